@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference TrafficEnv (build container only).
+
+TEST INFRASTRUCTURE.  Runs the reference's own `gym_traffic.envs.TrafficEnv`
+(/root/reference/gym_traffic/envs/traffic_env.py:221-394, imported in place through
+oracle/ref_loader.py) on a fixed list of scenarios and writes small `.npz` fixtures to
+tests/golden/.  A fixture is DATA only: the inputs that drive a run (tables, initial
+phase, per-tick actions, per-tick spawn roads) and the outputs the reference produced
+(per-tick ring indices, obs, rewards, done, waiting, passed_dst, car x/v/w by slot,
+remi rewards, cars_on_roads, trip times).  No reference source text is stored.
+
+Instrumentation (wrappers around reference callables; no reference logic is changed):
+  * `add_car` is wrapped to log the entry road of every car spawned by
+    `TrafficEnv.add_new_cars` (traffic_env.py:274-283) -> the spawn schedule.
+  * `advance_finished_cars` / `advance_hack` are wrapped to snapshot the state
+    between `move_cars` and the advance (the "mid" state) for kernel-level parity.
+
+Usage:  python oracle/gen_golden.py [--only NAME]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_loader import load_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# name -> scenario.  C = CAPACITY (slots per road); cars/road = C-2.
+SCENARIOS = {}
+
+
+def scen(name, **kw):
+    d = dict(m=2, n=2, L=250.0, C=20, seed=0, T=300, poisson=True, rate=0.5, lcps=0.12,
+             entry='all', learn_switch=False, mode='train', actions='random10',
+             remi_every=10, state_every=1, mid=False)
+    d.update(kw)
+    SCENARIOS[name] = d
+
+
+for _s in (0, 1):
+    for _p in (True, False):
+        for _c in (10, 20):
+            scen("g2x2_s%d_%s_c%d" % (_s, "poi" if _p else "reg", _c), seed=_s, poisson=_p, C=_c,
+                 mid=(_s == 0))
+scen("g2x2_fixedcycle", seed=2, actions='cycle3')
+scen("g2x2_learnswitch", seed=3, learn_switch=True)
+scen("g2x2_validate", seed=2, mode='validate', T=400)
+scen("g2x2_entry_one", seed=1, entry='one', lcps=0.3)
+scen("g2x2_const0_jam", seed=4, actions='const0', lcps=0.3, C=12, T=200)
+scen("g3x3_default", m=3, n=3, seed=0, T=400)
+scen("g3x2_rect", m=3, n=2, seed=5, T=240, C=16, lcps=0.2)
+scen("g4x4_cfg1", m=4, n=4, L=200.0, C=34, seed=0, T=300, lcps=0.3, state_every=10)
+scen("g16x16_cfg2_ints", m=16, n=16, L=400.0, C=66, seed=0, T=150, lcps=0.25, state_every=0)
+
+
+def run(name, sc, mods):
+    te = mods["gym_traffic.envs.traffic_env"]
+    rg = mods["gym_traffic.envs.roadgraph"]
+    gym = mods["gym"]
+    args = mods["args"]
+    FLAGS = args.FLAGS
+
+    te.CAPACITY = int(sc["C"])
+    args.update_flags(poisson=bool(sc["poisson"]), rate=float(sc["rate"]),
+                      local_cars_per_sec=float(sc["lcps"]), entry=sc["entry"],
+                      learn_switch=bool(sc["learn_switch"]), mode=sc["mode"])
+    C = te.CAPACITY
+    xi, vi, wi = te.xi, te.vi, te.wi
+
+    spawn_log = []          # roads of cars spawned in the current tick
+    in_spawn = [False]
+    mid_snap = {}
+
+    orig_add_car = te.add_car
+    orig_adv = te.advance_finished_cars
+    orig_hack = te.advance_hack
+
+    def logged_add_car(road, car, *a):
+        if in_spawn[0]:
+            spawn_log.append(int(road))
+        return orig_add_car(road, car, *a)
+
+    def snap_mid(state, leading, lastcar):
+        mid_snap["x"], mid_snap["v"] = live_planes(state, leading, lastcar, C, (xi, vi))
+
+    def logged_adv(dests, length, nexts, state, leading, lastcar, *a):
+        snap_mid(state, leading, lastcar)
+        return orig_adv(dests, length, nexts, state, leading, lastcar, *a)
+
+    def logged_hack(dests, length, nexts, state, leading, lastcar, *a):
+        snap_mid(state, leading, lastcar)
+        return orig_hack(dests, length, nexts, state, leading, lastcar, *a)
+
+    te.add_car = logged_add_car
+    te.advance_finished_cars = logged_adv
+    te.advance_hack = logged_hack
+    try:
+        env = gym.make('traffic-v0')
+        graph = rg.GridRoad(sc["m"], sc["n"], sc["L"])
+        env.set_graph(graph)
+        env.seed_generator(sc["seed"])
+        env.reset_entrypoints()
+        orig_add_new = env.add_new_cars
+
+        def add_new(tick):
+            in_spawn[0] = True
+            try:
+                return orig_add_new(tick)
+            finally:
+                in_spawn[0] = False
+        env.add_new_cars = add_new
+
+        np.random.seed(sc["seed"])
+        # np.empty garbage in never-written arrays is not a golden value: pin it to 0 so the
+        # fixture is reproducible (detected/rewards/waiting are stale-on-purpose in the
+        # reference, traffic_env.py:259-272; their *initial* content is undefined there).
+        env.state[:] = 0
+        env.rewards[:] = 0
+        env.reset()
+        Iq, r, R = graph.intersections, graph.train_roads, graph.roads
+        T = sc["T"]
+        arng = np.random.RandomState(sc["seed"] + 1)
+
+        out = dict(
+            phases=graph.phases.copy(), dest=graph.dest.copy(), nexts=graph.nexts.copy(),
+            entrypoints=graph.entrypoints.copy(), cars_per_sec=np.float64(FLAGS.cars_per_sec),
+            init_phase=env.current_phase.copy(),
+        )
+        actions = np.zeros((T, Iq), np.int32)
+        leading = np.zeros((T + 1, R), np.int32)
+        lastcar = np.zeros((T + 1, R), np.int32)
+        obs = np.zeros((T + 1, 2 * r + 2 * Iq), np.int32)
+        rewards = np.zeros((T + 1, Iq), np.float32)
+        waiting = np.zeros((T + 1, r), np.int32)
+        passed_dst = np.zeros((T + 1, Iq), np.uint8)
+        done = np.zeros(T + 1, np.uint8)
+        leader_x = np.zeros((T + 1, R), np.float32)
+        spawn_off = np.zeros(T + 1, np.int64)
+        spawn_road = []
+        se = sc["state_every"]
+        st_ticks, st_x, st_v, st_w, mid_x, mid_v = [], [], [], [], [], []
+        remi_ticks, remi_rew, cor = [], [], []
+        trip_count = np.zeros(T + 1, np.int64)
+
+        def record(k):
+            leading[k] = env.leading
+            lastcar[k] = env.lastcar
+            obs[k] = env.obs
+            rewards[k] = env.rewards
+            waiting[k] = env.waiting
+            passed_dst[k] = env.passed_dst
+            leader_x[k] = env.state[np.arange(R), xi, env.leading]
+            if se and k % se == 0:
+                x, v, w = live_planes(env.state, env.leading, env.lastcar, C, (xi, vi, wi))
+                st_ticks.append(k)
+                st_x.append(x)
+                st_v.append(v)
+                st_w.append(w)
+
+        env.waiting[:] = 0
+        record(0)
+        cur = None
+        for t in range(T):
+            if sc["actions"] == 'random10':
+                if t % 10 == 0:
+                    cur = arng.randint(2, size=Iq).astype(np.int32)
+            elif sc["actions"] == 'cycle3':
+                cur = np.full(Iq, int((t % 6) >= 3), np.int32)
+            elif sc["actions"] == 'const0':
+                cur = np.zeros(Iq, np.int32)
+            actions[t] = cur
+            del spawn_log[:]
+            # the reference accepts any dtype here (bool from a3c, float64 from const0)
+            _, _, d, _ = env.step(cur.copy())
+            spawn_road.extend(spawn_log)
+            spawn_off[t + 1] = len(spawn_road)
+            done[t + 1] = bool(d)
+            trip_count[t + 1] = len(env.trip_times)
+            if sc["mid"]:
+                mid_x.append(mid_snap["x"])
+                mid_v.append(mid_snap["v"])
+            record(t + 1)
+            if sc["remi_every"] and (t + 1) % sc["remi_every"] == 0:
+                cor.append(env.cars_on_roads().copy())
+                remi_rew.append(env.remi_reward().copy())
+                remi_ticks.append(t + 1)
+        out.update(actions=actions, leading=leading, lastcar=lastcar, obs=obs, rewards=rewards,
+                   waiting=waiting, passed_dst=passed_dst, done=done, leader_x=leader_x,
+                   spawn_off=spawn_off, spawn_road=np.asarray(spawn_road, np.int32),
+                   generated_cars=np.int64(env.generated_cars),
+                   remi_ticks=np.asarray(remi_ticks, np.int64),
+                   remi_rewards=np.asarray(remi_rew, np.float32).reshape(len(remi_ticks), Iq),
+                   cars_on_roads=np.asarray(cor, np.int32).reshape(len(remi_ticks), sc["m"], sc["n"], 4),
+                   trip_times=np.asarray(env.trip_times, np.float64), trip_count=trip_count)
+        if se:
+            out.update(state_ticks=np.asarray(st_ticks, np.int64), state_x=np.stack(st_x),
+                       state_v=np.stack(st_v), state_w=np.stack(st_w))
+        if sc["mid"]:
+            out.update(mid_x=np.stack(mid_x), mid_v=np.stack(mid_v))
+        out["scenario"] = np.array(json.dumps(sc))
+        out["numpy_version"] = np.array(np.__version__)
+        return out
+    finally:
+        te.add_car = orig_add_car
+        te.advance_finished_cars = orig_adv
+        te.advance_hack = orig_hack
+
+
+def live_planes(state, leading, lastcar, C, planes):
+    """Copies of the requested parameter planes [R, C] with every slot that is neither a live
+    car nor the fake leader set to 0 (dead slots / slot 0 hold garbage in the reference)."""
+    R = state.shape[0]
+    slots = np.arange(C)[None, :]
+    ld = leading[:, None]
+    lc = lastcar[:, None]
+    unwrapped = (slots > ld) & (slots <= lc)
+    wrapped = (slots > ld) | ((slots >= 1) & (slots <= lc))
+    live = np.where(ld <= lc, unwrapped, wrapped) & (ld != lc)
+    keep = live | (slots == ld)
+    outs = []
+    for p in planes:
+        a = state[:, p, :].copy()
+        a[~keep] = 0
+        outs.append(a)
+    return outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    mods = load_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for name, sc in SCENARIOS.items():
+        if a.only and a.only != name:
+            continue
+        out = run(name, sc, mods)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-24s T=%d spawned=%d overflow_ticks=%d trips=%d  %.1f KB" % (
+            name, sc["T"], int(out["generated_cars"]), int(out["done"].sum()),
+            len(out["trip_times"]), os.path.getsize(path) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

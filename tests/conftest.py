@@ -1,0 +1,73 @@
+"""Shared test plumbing.
+
+Markers: `gpu` = needs a real MI355X (run by the driver with `-m gpu`); everything else runs on
+CPU.  The oracle (oracle/) is the CHECKER in these tests, never the thing under test on the
+product path.
+"""
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "traffic-env_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (HIP kernels run)")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden(object):
+    """One captured reference run (see oracle/gen_golden.py for the field list)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.sc = json.loads(str(self.z["scenario"]))
+        self._arr = {}
+
+    def __getitem__(self, k):
+        if k not in self._arr:          # NpzFile decompresses on every access: keep the array
+            self._arr[k] = self.z[k]
+        return self._arr[k]
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def spawns(self, t):
+        off = self["spawn_off"]
+        return self["spawn_road"][off[t]:off[t + 1]]
+
+
+@pytest.fixture(scope="session")
+def golden_cache():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def ulp_diff(a, b):
+    """Distance in units-in-the-last-place between two float32 arrays (same-sign-aware)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)

@@ -1,0 +1,157 @@
+/*
+ * tfx.h - C ABI of the MI355X-native IDM traffic-env step ("tfx" = traffic step).
+ *
+ * This is the drop-in boundary for the hot path of samanklesaria/traffic-env.  The reference has
+ * no FFI of its own: the boundary it offers is the set of numba-typed kernels in
+ * gym_traffic/envs/traffic_env.py (each @jit signature is a C-like contract: typed, in-place,
+ * caller-owned arrays) plus the TrafficEnv methods that sequence them.  Every entry point below
+ * cites the reference interface it replaces.  All arrays gain a leading E (batched env)
+ * dimension; E = 1 reproduces the reference object.
+ *
+ * Conventions
+ *   - plain C, no torch/HIP types in signatures: device pointers are `void*`-compatible raw
+ *     pointers, the stream is a `void*` holding a hipStream_t (NULL = default stream);
+ *   - every call returns 0 on success, a negative TFX_E* code on failure; the message for the
+ *     calling thread is available from tfx_last_error(); nothing throws, nothing calls exit();
+ *   - all state arrays are owned by the caller (the Python env keeps them as PyTorch-ROCm
+ *     tensors) and are mutated in place, exactly like the reference's NumPy arrays
+ *     (traffic_env.py:361-382); the handle owns only static road tables and per-road scratch;
+ *   - no global mutable state: handles are independent and may be driven from different host
+ *     threads (the reference's kernels are nogil and A3C steps envs from threads, a3c.py:69-72).
+ *
+ * Device data layout (all little-endian, C-contiguous)
+ *   state      float32 [E][R][P][C]   P = 2 planes (x, v) or 3 (x, v, w); slot s of road e is the
+ *                                     reference's state[e, {xi,vi,wi}, s] (traffic_env.py:34,364).
+ *                                     The other 7 per-car parameters are per-archetype constants
+ *                                     (traffic_env.py:35-43) and live in tfx_config.
+ *   leading    int32   [E][R]         slot of the fake leader  (README.md:14-23 of the reference)
+ *   lastcar    int32   [E][R]         slot of the last car; == leading when the road is empty
+ *   obs        int32   [E][2r+2I]     passed | detected | current_phase | elapsed (traffic_env.py:370-376)
+ *   rewards    float32 [E][I]
+ *   waiting    int32   [E][r]
+ *   passed_dst uint8   [E][I]
+ *   done_tick  int32   [E]            tick index (+1) of the last tick in which the env overflowed
+ */
+#ifndef TFX_H
+#define TFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFX_ABI_VERSION 1
+#define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
+
+enum {
+  TFX_OK = 0,
+  TFX_EINVAL = -1,   /* bad argument / unsupported configuration */
+  TFX_ESTATE = -2,   /* call order (e.g. step before bind_buffers) */
+  TFX_EDEVICE = -3,  /* HIP runtime error (message has the HIP error string) */
+  TFX_ENOMEM = -4
+};
+
+/* how the per-tick light action is obtained (TrafficEnv._step(action), traffic_env.py:224-232) */
+enum {
+  TFX_ACTION_BUFFER = 0,    /* int32 [n_ticks or 1][E][I] device buffer */
+  TFX_ACTION_BROADCAST = 1, /* int32 [n_ticks or 1][I]: same action for every env */
+  TFX_ACTION_CYCLE = 2      /* on-device fixed cycle: a = ((tick + env % period) / period) & 1
+                               (algorithms/fixed.py:6-7 with spacing = period, env-staggered) */
+};
+
+/* how cars enter (TrafficEnv.add_new_cars, traffic_env.py:274-283) */
+enum {
+  TFX_SPAWN_NONE = 0,
+  TFX_SPAWN_COUNTS = 1,  /* int32 [n_ticks or 1][E][n_entry]: cars to add to entry road j this tick
+                            (host replays the reference's RandomState schedule) */
+  TFX_SPAWN_PERIODIC = 2 /* on-device fixed rate: entry road e gets one car when
+                            tick % period == e % period */
+};
+
+typedef struct tfx_config {
+  int32_t m, n;          /* GridRoad(m, n, l): I = m*n, r = 4I, R = r + 2m + 2n (roadgraph.py:26-33) */
+  int32_t capacity;      /* CAPACITY, slots per road incl. slot 0 and the fake leader (traffic_env.py:24) */
+  int32_t n_envs;        /* E */
+  int32_t planes;        /* 2 or 3 */
+  float length;          /* graph.len */
+  float rate;            /* FLAGS.rate, seconds per tick (traffic_env.py:12) */
+  /* the archetype, traffic_env.py:35-43 */
+  float car_v, car_l, car_a, car_delta, car_v0, car_b, car_T, car_s0;
+  int32_t yellow_ticks;  /* YELLOW_TICKS (traffic_env.py:21) */
+  float thresh;          /* THRESH (traffic_env.py:17) */
+  float detect_dist;     /* the 10 of `length - 10` (traffic_env.py:201) */
+  float overflow_penalty;/* OVERFLOW_PENALTY (traffic_env.py:23) */
+  float eps;             /* EPS (traffic_env.py:25) */
+  int32_t learn_switch;  /* FLAGS.learn_switch (traffic_env.py:15,225-230) */
+  int32_t validate;      /* FLAGS.mode == 'validate': advance_hack records trip times (traffic_env.py:240-242) */
+  uint32_t entry_spec;   /* generate_entrypoints(spec) bit mask (roadgraph.py:42-51) */
+} tfx_config;
+
+typedef struct tfx_buffers {
+  float *state;
+  int32_t *leading;
+  int32_t *lastcar;
+  int32_t *obs;
+  float *rewards;
+  int32_t *waiting;
+  uint8_t *passed_dst;
+  int32_t *done_tick;
+  float *trip_times;   /* [E][trip_cap] or NULL; (tick - w)/2 of cars leaving the map (traffic_env.py:154) */
+  int32_t *n_trips;    /* [E] or NULL */
+  int32_t trip_cap;
+} tfx_buffers;
+
+typedef struct tfx_handle_s *tfx_handle;
+
+int tfx_abi_version(void);
+const char *tfx_last_error(void);
+
+/* TrafficEnv.set_graph (traffic_env.py:361-382) + GridRoad tables (roadgraph.py:26-64): builds
+ * dest/phases/nexts/entrypoints for the grid on the device.  */
+int tfx_create(const tfx_config *cfg, tfx_handle *out);
+int tfx_destroy(tfx_handle h);
+/* sizes for the caller's allocations */
+int tfx_dims(tfx_handle h, int32_t *I, int32_t *r, int32_t *R, int32_t *n_entry);
+/* copies the int32[R] tables (host pointers, any may be NULL); entrypoints is int32[n_entry] */
+int tfx_tables(tfx_handle h, int32_t *dest, int32_t *phases, int32_t *nexts, int32_t *entrypoints);
+int tfx_bind_buffers(tfx_handle h, const tfx_buffers *b);
+
+/* TrafficEnv._reset (traffic_env.py:259-272).  phase_init: device int32 [E][I] (replaces
+ * action_space.sample()).  detected / rewards are left stale, as in the reference. */
+int tfx_reset(tfx_handle h, const int32_t *phase_init, void *stream);
+/* Call after writing state/leading/lastcar from outside (tests, checkpoint restore): rebuilds the
+ * per-road tail cache the light kernel reads. */
+int tfx_refresh(tfx_handle h, void *stream);
+
+int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick);
+int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick);
+
+/* TrafficEnv._step (traffic_env.py:224-248), n_ticks times: phase/elapsed update, spawns,
+ * move_cars, advance_finished_cars | advance_hack, steps += 1. */
+int tfx_step(tfx_handle h, int32_t n_ticks, void *stream);
+/* The two halves on their own, for kernel-level parity tests:
+ * move_cars (traffic_env.py:187-212, incl. update_lights :81-94; also applies the phase update and
+ * the spawns of the current tick) and advance_finished_cars / advance_hack (:117-157). */
+int tfx_move_cars(tfx_handle h, void *stream);
+int tfx_advance_finished_cars(tfx_handle h, void *stream);
+
+/* remi (traffic_env.py:64-78) via TrafficEnv.remi_reward (:384-387) */
+int tfx_remi(tfx_handle h, void *stream);
+/* cars_on_roads (traffic_env.py:214-218): out device int32 [E][R] */
+int tfx_cars_on_roads(tfx_handle h, int32_t *out, void *stream);
+/* done flag of _step (traffic_env.py:246-248): out[k] = env k overflowed in a tick >= since_tick */
+int tfx_done(tfx_handle h, uint8_t *out, int32_t since_tick, void *stream);
+
+int tfx_get_tick(tfx_handle h, int32_t *tick);              /* TrafficEnv.steps */
+int tfx_set_tick(tfx_handle h, int32_t tick);               /* also clears the per-env overflow stamps */
+/* live cars advanced by move_cars since the last tfx_reset_counters (synchronises the stream) */
+int tfx_vehicle_updates(tfx_handle h, uint64_t *out, void *stream);
+int tfx_reset_counters(tfx_handle h, void *stream);
+/* launch geometry of the move kernel, for the roofline report */
+int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFX_H */

@@ -1,0 +1,216 @@
+"""TfxEngine: E batched traffic envs resident on one MI355X.
+
+Owns the device buffers (PyTorch-ROCm tensors - used for memory and streams only) and drives the
+HIP kernels through the C ABI (include/tfx.h, csrc/tfx_hip.hip).  Both front-ends sit on top of it:
+`TrafficEnv` (the reference's single-env gym object, NumPy in / NumPy out) and `TrafficVecEnv`
+(tensors in / tensors out for batched RL rollouts).
+
+State layout = the reference's arrays with a leading env dimension (traffic_env.py:361-382):
+    state [E,R,P,C] f32 (P planes: x, v[, w])   leading/lastcar [E,R] i32   obs [E,2r+2I] i32
+    rewards [E,I] f32   waiting [E,r] i32   passed_dst [E,I] u8   done_tick [E] i32
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+# the single archetype of the reference (traffic_env.py:35-43)
+ARCHETYPE = dict(car_v=11.11, car_l=4.0, car_a=3.0, car_delta=4.0, car_v0=13.89, car_b=6.0,
+                 car_T=2.0, car_s0=1.0)
+# module constants of the reference (traffic_env.py:17-25)
+CONSTANTS = dict(yellow_ticks=6, thresh=0.2, detect_dist=10.0, overflow_penalty=10.0, eps=1e-8)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class TfxEngine(object):
+    def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
+                 validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None):
+        if not torch.cuda.is_available():
+            raise nat.TfxError("no GPU visible: the traffic env step runs on MI355X only (no CPU fallback)")
+        self.lib = nat.lib()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.m, self.n, self.C, self.E = int(m), int(n), int(capacity), int(n_envs)
+        self.P = int(planes) if planes else (3 if validate else 2)
+        cfg = nat.TfxConfig()
+        cfg.m, cfg.n, cfg.capacity, cfg.n_envs, cfg.planes = self.m, self.n, self.C, self.E, self.P
+        cfg.length, cfg.rate = float(length), float(rate)
+        for k, v in ARCHETYPE.items():
+            setattr(cfg, k, v)
+        for k, v in CONSTANTS.items():
+            setattr(cfg, k, v)
+        cfg.learn_switch, cfg.validate = int(bool(learn_switch)), int(bool(validate))
+        cfg.entry_spec = int(entry_spec)
+        self.cfg = cfg
+        self.validate = bool(validate)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        dims = [C.c_int32() for _ in range(4)]
+        nat.check(self.lib.tfx_dims(h, *[C.byref(d) for d in dims]))
+        self.I, self.r, self.R, self.n_entry = [int(d.value) for d in dims]
+        self.obs_len = 2 * self.r + 2 * self.I
+        self.dest = np.zeros(self.R, np.int32)
+        self.phases = np.zeros(self.R, np.int32)
+        self.nexts = np.zeros(self.R, np.int32)
+        self.entrypoints = np.zeros(max(1, self.n_entry), np.int32)
+        nat.check(self.lib.tfx_tables(h, *[a.ctypes.data_as(C.c_void_p) for a in
+                                           (self.dest, self.phases, self.nexts, self.entrypoints)]))
+        self.entrypoints = self.entrypoints[:self.n_entry]
+        self.entry_index = {int(rd): j for j, rd in enumerate(self.entrypoints)}
+
+        E, R, P, Cc, I, r = self.E, self.R, self.P, self.C, self.I, self.r
+        dev = self.device
+        # zeros, not empty: the reference leaves these to np.empty garbage; a defined start keeps
+        # runs reproducible (dead slots are never read)
+        self.state = torch.zeros((E, R, P, Cc), dtype=torch.float32, device=dev)
+        self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
+        self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
+        self.obs = torch.zeros((E, self.obs_len), dtype=torch.int32, device=dev)
+        self.rewards = torch.zeros((E, I), dtype=torch.float32, device=dev)
+        self.waiting = torch.zeros((E, r), dtype=torch.int32, device=dev)
+        self.passed_dst = torch.zeros((E, I), dtype=torch.uint8, device=dev)
+        self.done_tick = torch.zeros((E,), dtype=torch.int32, device=dev)
+        self.done = torch.zeros((E,), dtype=torch.uint8, device=dev)
+        self.trip_cap = int(trip_cap)
+        self.trip_times = torch.zeros((E, self.trip_cap), dtype=torch.float32, device=dev) if validate else None
+        self.n_trips = torch.zeros((E,), dtype=torch.int32, device=dev) if validate else None
+        self._cars = torch.zeros((E, R), dtype=torch.int32, device=dev)
+        b = nat.TfxBuffers()
+        b.state, b.leading, b.lastcar = _ptr(self.state), _ptr(self.leading), _ptr(self.lastcar)
+        b.obs, b.rewards, b.waiting = _ptr(self.obs), _ptr(self.rewards), _ptr(self.waiting)
+        b.passed_dst, b.done_tick = _ptr(self.passed_dst), _ptr(self.done_tick)
+        b.trip_times, b.n_trips, b.trip_cap = _ptr(self.trip_times), _ptr(self.n_trips), self.trip_cap
+        nat.check(self.lib.tfx_bind_buffers(h, C.byref(b)))
+        self._action_buf = None
+        self._spawn_buf = None
+        self.tick = 0
+        # views with the reference's attribute names (traffic_env.py:372-376)
+        self.passed = self.obs[:, :r]
+        self.detected = self.obs[:, r:2 * r]
+        self.current_phase = self.obs[:, 2 * r:2 * r + I]
+        self.elapsed = self.obs[:, 2 * r + I:]
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.tfx_destroy(h)
+            except Exception:
+                pass
+
+    # ---- stream plumbing: kernels go on torch's current stream --------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- the reference's operations ----------------------------------------------------------
+    def reset(self, phase_init):
+        """TrafficEnv._reset (traffic_env.py:259-272); phase_init int[E,I] or [I]."""
+        ph = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(
+            np.asarray(phase_init, np.int32), (self.E, self.I)))).to(self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_reset(self.h, _ptr(ph), self._stream()))
+        self._keep = ph
+        self.tick = 0
+        self.done.zero_()
+
+    def refresh(self):
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_refresh(self.h, self._stream()))
+
+    def set_actions(self, actions=None, cycle_period=None, per_tick=False):
+        """actions: int tensor/array [E,I] (or [I] broadcast; with per_tick a leading n_ticks
+        dim), or cycle_period for the on-device fixed cycle."""
+        if cycle_period is not None:
+            nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_CYCLE, None, int(cycle_period), 0))
+            return
+        a = self._to_dev_i32(actions)
+        base = a.dim() - (1 if per_tick else 0)
+        mode = nat.ACTION_BROADCAST if base == 1 else nat.ACTION_BUFFER
+        self._action_buf = a
+        nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, int(bool(per_tick))))
+
+    def set_spawns(self, counts=None, period=None, per_tick=False):
+        """counts: int [E,n_entry] (with per_tick: [n_ticks,E,n_entry]); period: on-device
+        one-car-every-`period`-ticks per entry road; neither: no spawns."""
+        if period is not None:
+            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_PERIODIC, None, int(period), 0))
+        elif counts is not None:
+            c = self._to_dev_i32(counts)
+            self._spawn_buf = c
+            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, int(bool(per_tick))))
+        else:
+            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_NONE, None, 0, 0))
+
+    def _to_dev_i32(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+
+    def step(self, n_ticks=1):
+        """n_ticks x TrafficEnv._step (traffic_env.py:224-248) with the inputs set by
+        set_actions / set_spawns.  Updates `done` (overflow in any of these ticks)."""
+        first = self.tick
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_step(self.h, int(n_ticks), self._stream()))
+            self.tick += int(n_ticks)
+            nat.check(self.lib.tfx_done(self.h, _ptr(self.done), first, self._stream()))
+
+    def move_cars(self):
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_move_cars(self.h, self._stream()))
+
+    def advance_finished_cars(self):
+        first = self.tick
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_advance_finished_cars(self.h, self._stream()))
+            self.tick += 1
+            nat.check(self.lib.tfx_done(self.h, _ptr(self.done), first, self._stream()))
+
+    def remi_reward(self):
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_remi(self.h, self._stream()))
+        return self.rewards
+
+    def cars_on_roads_flat(self):
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_cars_on_roads(self.h, _ptr(self._cars), self._stream()))
+        return self._cars
+
+    def cars_on_roads(self):
+        """[E, m, n, 4] as TrafficEnv.cars_on_roads (traffic_env.py:255-257)."""
+        flat = self.cars_on_roads_flat()[:, :self.r]
+        return flat.reshape(self.E, 4, self.m, self.n).permute(0, 2, 3, 1)
+
+    def set_tick(self, tick):
+        nat.check(self.lib.tfx_set_tick(self.h, int(tick)))
+        self.tick = int(tick)
+
+    def vehicle_updates(self):
+        out = C.c_uint64()
+        nat.check(self.lib.tfx_vehicle_updates(self.h, C.byref(out), self._stream()))
+        return int(out.value)
+
+    def reset_counters(self):
+        nat.check(self.lib.tfx_reset_counters(self.h, self._stream()))
+
+    def launch_info(self):
+        v = [C.c_int32() for _ in range(3)]
+        nat.check(self.lib.tfx_launch_info(self.h, *[C.byref(x) for x in v]))
+        return dict(grid=v[0].value, block=v[1].value, waves_per_road=v[2].value)
+
+    # ---- bulk state import (tests, checkpoint restore) ----------------------------------------
+    def load_state(self, x, v, leading, lastcar, w=None):
+        """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
+        self.state[:, :, 0, :] = torch.as_tensor(np.asarray(x, np.float32)).to(self.device)
+        self.state[:, :, 1, :] = torch.as_tensor(np.asarray(v, np.float32)).to(self.device)
+        if self.P == 3 and w is not None:
+            self.state[:, :, 2, :] = torch.as_tensor(np.asarray(w, np.float32)).to(self.device)
+        self.leading.copy_(torch.as_tensor(np.asarray(leading, np.int32)).to(self.device))
+        self.lastcar.copy_(torch.as_tensor(np.asarray(lastcar, np.int32)).to(self.device))
+        self.refresh()

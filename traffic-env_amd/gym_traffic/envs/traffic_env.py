@@ -1,0 +1,267 @@
+"""TrafficEnv: the reference's gym environment (traffic_env.py:221-394), stepped on the GPU.
+
+Drop-in surface: `set_graph, seed_generator, reset_entrypoints, reset/_reset, step/_step,
+render/_render, cars_on_roads, remi_reward` and the attributes agents and wrappers read (`obs,
+rewards, passed, detected, current_phase, elapsed, waiting, passed_dst, leading, lastcar, state,
+trip_times, steps, generated_cars, graph, action_space, observation_space, reward_size`).  NumPy in,
+NumPy out, one env - exactly what algorithms/*.py and traffic_test.py's wrappers expect.  All
+simulation state lives in device tensors owned by a TfxEngine (gym_traffic/core.py); every tick is
+two HIP kernels.  There is no CPU step path.
+
+Differences from the reference that a caller can observe:
+  * `CAPACITY` is a constructor/`set_graph` parameter (module default 20) instead of a frozen
+    module constant, so the 8/32/64/128-cars-per-road configurations exist;
+  * `obs`/`rewards` are still live buffers re-used every step, but `state`, `leading`, `lastcar`,
+    `waiting`, `passed_dst` are device-backed views: reading copies from the GPU, item assignment
+    writes through (Remi's `passed_dst[:] = False`, traffic_test.py:63, keeps working);
+  * arrays the reference leaves to `np.empty` garbage start at 0.
+"""
+import time
+
+import gym
+import numpy as np
+
+from gym_traffic.spaces.gspace import GSpace
+from gym_traffic.flags import FLAGS, flag
+from gym_traffic.spawner import SpawnSchedule, counts_from_roads
+
+# module constants, same names as the reference (traffic_env.py:17-25)
+THRESH = 0.2
+PASSING_REWARD = 0
+YELLOW_TICKS = 6
+DECEL_PENALTY = False
+OVERFLOW_PENALTY = 10
+CAPACITY = 20
+EPS = 1e-8
+
+# car-parameter indices of the reference's state array (traffic_env.py:33-34); this package stores
+# the x, v (and w) planes per car, the other seven are the archetype's constants
+params = 10
+xi, vi, li, ai, deltai, v0i, bi, ti, s0i, wi = range(params)
+archetypes = np.zeros((1, params), dtype=np.float32)
+archetypes[0, [vi, ai, deltai, v0i, li, bi, ti, s0i]] = [11.11, 3, 4, 13.89, 4, 6, 2, 1]
+
+
+def inv_popcount(spec):
+    """Open sides of the grid for entry spec `spec` (traffic_env.py:180-185): 4 - popcount(spec & 15)."""
+    return 4 - bin(int(spec) & 0b1111).count('1')
+
+
+def cars_on_roads(leading, lastcar, capacity=None):
+    """traffic_env.py:214-218 on host arrays (used by callers that import it, e.g. greedy.py:4)."""
+    cap = CAPACITY if capacity is None else capacity
+    leading, lastcar = np.asarray(leading), np.asarray(lastcar)
+    return (lastcar - leading + (leading > lastcar) * np.int32(cap - 1)).astype(np.int32)
+
+
+class DeviceView(object):
+    """NumPy-looking window on one env's slice of a device tensor: reads download, item
+    assignment uploads (and lets the engine rebuild what it caches)."""
+
+    def __init__(self, tensor_fn, after_write=None, dtype=None):
+        self._t = tensor_fn
+        self._after = after_write
+        self._dtype = dtype
+
+    def numpy(self):
+        a = self._t().detach().cpu().numpy()
+        return a.astype(self._dtype) if self._dtype is not None else a
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    def __setitem__(self, idx, value):
+        import torch
+        a = self._t().detach().cpu().numpy().copy()
+        a[idx] = value
+        self._t().copy_(torch.as_tensor(a))
+        if self._after:
+            self._after()
+
+    def __len__(self):
+        return self._t().shape[0]
+
+    @property
+    def shape(self):
+        return tuple(self._t().shape)
+
+    def copy(self):
+        return self.numpy().copy()
+
+    def tolist(self):
+        return self.numpy().tolist()
+
+    def __eq__(self, other):
+        return self.numpy() == other
+
+    def __repr__(self):
+        return "DeviceView(%r)" % (self.numpy(),)
+
+
+class TrafficEnv(gym.Env):
+    metadata = {'render.modes': ['human', 'rgb_array']}
+
+    def __init__(self, capacity=None, device=None):
+        self.capacity = capacity
+        self.device = device
+        self.engine = None
+        self.viewer = None
+        self.graph = None
+
+    # ---- construction (traffic_env.py:361-382) ------------------------------------------------
+    def set_graph(self, graph, capacity=None):
+        from gym_traffic.core import TfxEngine
+        self.viewer = None
+        self.graph = graph
+        self.capacity = int(capacity or self.capacity or CAPACITY)
+        self._validate = flag('mode', 'train') == 'validate'
+        self._spec = getattr(self, '_spec', 0)
+        self._build_engine()
+        r, i = graph.train_roads, graph.intersections
+        self.action_space = GSpace([i], np.int32(2))
+        self.observation_space = GSpace([2 * r + 2 * i], np.int32(1))
+        self.obs = np.zeros([2 * r + 2 * i], dtype=np.int32)
+        self.passed = self.obs[:r]
+        self.detected = self.obs[r:r + r]
+        self.current_phase = self.obs[r + r:r + r + i]
+        self.elapsed = self.obs[-i:]
+        self.rewards = np.zeros(i, dtype=np.float32)
+        self.reward_size = self.rewards.size
+        self.trip_times = []
+        self.steps = np.float32(0)
+        self.generated_cars = 0
+        self.reset_entrypoints()
+
+    def _build_engine(self):
+        from gym_traffic.core import TfxEngine
+        g = self.graph
+        self.engine = TfxEngine(g.m, g.n, float(g.len), self.capacity, n_envs=1,
+                                rate=float(FLAGS.rate), learn_switch=bool(flag('learn_switch', False)),
+                                validate=self._validate, entry_spec=self._spec, planes=3,
+                                device=self.device)
+        self._built = (float(FLAGS.rate), bool(flag('learn_switch', False)), self._validate, self._spec)
+        eng = self.engine
+        self.state = DeviceView(lambda: eng.state[0], eng.refresh)            # [R, 3, C]: x, v, w planes
+        self.leading = DeviceView(lambda: eng.leading[0], eng.refresh)
+        self.lastcar = DeviceView(lambda: eng.lastcar[0], eng.refresh)
+        self.waiting = DeviceView(lambda: eng.waiting[0])
+        self.passed_dst = DeviceView(lambda: eng.passed_dst[0], dtype=np.bool_)
+        self._spawn_counts = np.zeros((1, max(1, eng.n_entry)), np.int32)
+
+    def _sync_flags(self):
+        """The reference re-reads FLAGS.rate / learn_switch / mode on every tick (traffic_env.py:
+        225,237,240).  They are baked into the device config, so a change rebuilds the engine
+        around the current state."""
+        now = (float(FLAGS.rate), bool(flag('learn_switch', False)),
+               flag('mode', 'train') == 'validate', self._spec)
+        if now == self._built:
+            return
+        old = self.engine
+        snap = [t.clone() for t in (old.state, old.leading, old.lastcar, old.obs, old.rewards,
+                                    old.waiting, old.passed_dst)]
+        tick = old.tick
+        self._validate = now[2]
+        self._build_engine()
+        eng = self.engine
+        for dst, src in zip((eng.state, eng.leading, eng.lastcar, eng.obs, eng.rewards, eng.waiting,
+                             eng.passed_dst), snap):
+            dst.copy_(src)
+        eng.refresh()
+        eng.set_tick(tick)
+
+    def seed_generator(self, seed=None):
+        self.rand = np.random.RandomState(seed)
+        self._schedule = None   # created lazily: entrypoints / cars_per_sec may still change
+
+    def reset_entrypoints(self):
+        entry = flag('entry', 'all')
+        if entry == "random":
+            spec = int(np.random.randint(0b1111, dtype='uint32'))
+        elif entry == "one":
+            spec = 0b1110
+        else:
+            spec = 0
+        self._spec = spec
+        self.graph.generate_entrypoints(spec)
+        self.cars_per_sec = FLAGS.local_cars_per_sec * self.graph.m * inv_popcount(spec)
+        # the reference publishes this through the global flags (traffic_env.py:394); keep doing so
+        FLAGS.cars_per_sec = self.cars_per_sec
+        if self.engine is not None and self._built[3] != spec:
+            self._sync_flags()
+        if getattr(self, '_schedule', None) is not None:
+            self._schedule.entrypoints = self.graph.entrypoints
+
+    def _spawns(self):
+        if getattr(self, '_schedule', None) is None:
+            if not hasattr(self, 'rand'):
+                self.seed_generator()
+            self._schedule = SpawnSchedule(self.rand, flag('poisson', True), self.graph.entrypoints,
+                                           lambda: (FLAGS.cars_per_sec, FLAGS.rate),
+                                           n_archetypes=archetypes.shape[0])
+        return self._schedule.next_tick()
+
+    # ---- gym protocol -------------------------------------------------------------------------
+    def _reset(self):
+        self._sync_flags()
+        self.steps = np.float32(0)
+        self.generated_cars = 0
+        self.engine.reset(self.action_space.sample())
+        self._pull()
+        return self.obs
+
+    def _step(self, action):
+        self._sync_flags()
+        eng = self.engine
+        roads = self._spawns()
+        self.generated_cars += len(roads)
+        counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._spawn_counts[0])
+        eng.set_spawns(counts=self._spawn_counts)
+        # `current_phase[:] = action` / logical_xor semantics: any dtype, truthiness for the change
+        act = np.asarray(action)
+        if flag('learn_switch', False):
+            act = (act != 0)
+        eng.set_actions(act.astype(np.int32).reshape(1, -1))
+        ntrips = int(eng.n_trips[0]) if self._validate else 0
+        eng.step(1)
+        self.steps += 1
+        overflowed = self._pull()
+        if self._validate:
+            new = int(eng.n_trips[0])
+            if new > ntrips:
+                self.trip_times.extend(eng.trip_times[0, ntrips:new].cpu().numpy())
+        return self.obs, self.rewards, overflowed, None
+
+    def _pull(self):
+        eng = self.engine
+        self.obs[:] = eng.obs[0].cpu().numpy()
+        self.rewards[:] = eng.rewards[0].cpu().numpy()
+        return bool(eng.done[0].item())
+
+    def cars_on_roads(self):
+        return self.engine.cars_on_roads()[0].cpu().numpy()
+
+    def remi_reward(self):
+        self.rewards[:] = self.engine.remi_reward()[0].cpu().numpy()
+        return self.rewards
+
+    # ---- rendering (traffic_env.py:285-359; pyglet is not available -> matplotlib) -------------
+    def _render(self, mode='human', close=False):
+        from gym_traffic.render import MatplotlibViewer
+        if close:
+            if self.viewer is not None:
+                self.viewer.close()
+                self.viewer = None
+            return
+        if self.viewer is None:
+            self.viewer = MatplotlibViewer(self.graph)
+        eng = self.engine
+        frame = self.viewer.draw(self.graph, eng.state[0].cpu().numpy(), eng.leading[0].cpu().numpy(),
+                                 eng.lastcar[0].cpu().numpy(), self.current_phase, self.elapsed,
+                                 YELLOW_TICKS, float(archetypes[0, li]), mode)
+        if mode == 'human':
+            time.sleep(FLAGS.rate / 2)
+        return frame

@@ -1,0 +1,85 @@
+"""TrafficVecEnv: E independent traffic envs stepped together on one MI355X, tensors in/out.
+
+This is the batched form of the reference's TrafficEnv (traffic_env.py:221-394) for RL rollouts:
+the same tick semantics per env, every env's arrays stacked along a leading dimension, no host
+round trip inside `step`.  Spawns come either from per-env replicas of the reference's seeded
+generators (`spawn='poisson'|'regular'`: host RandomState schedules, bit-identical per env to a
+reference env seeded `seed + env_id`) or from the on-device fixed-rate rule (`spawn='periodic'`).
+Sharding across GPUs is by env id (gym_traffic/distributed.py); envs share nothing.
+"""
+import numpy as np
+import torch
+
+from gym_traffic.core import TfxEngine
+from gym_traffic.envs.roadgraph import GridRoad
+from gym_traffic.spawner import SpawnSchedule, counts_from_roads
+
+
+class TrafficVecEnv(object):
+    def __init__(self, num_envs, m, n, length, capacity=20, rate=0.5, local_cars_per_sec=0.12,
+                 spawn='poisson', spawn_period=8, entry_spec=0, learn_switch=False, validate=False,
+                 seed=0, env_id_offset=0, device=None):
+        self.num_envs = int(num_envs)
+        self.graph = GridRoad(m, n, length)
+        self.graph.generate_entrypoints(entry_spec)
+        self.engine = TfxEngine(m, n, length, capacity, n_envs=num_envs, rate=rate,
+                                learn_switch=learn_switch, validate=validate,
+                                entry_spec=entry_spec, device=device)
+        self.rate = float(rate)
+        open_sides = 4 - bin(int(entry_spec) & 15).count('1')
+        self.cars_per_sec = local_cars_per_sec * m * open_sides
+        self.spawn = spawn
+        self.env_id_offset = int(env_id_offset)
+        eng = self.engine
+        if spawn in ('poisson', 'regular'):
+            # env k of this shard is global env (env_id_offset + k): its stream does not depend on
+            # how the envs are sharded over GPUs
+            self._sched = [SpawnSchedule(np.random.RandomState(seed + self.env_id_offset + k),
+                                         spawn == 'poisson', self.graph.entrypoints,
+                                         lambda: (self.cars_per_sec, self.rate))
+                           for k in range(self.num_envs)]
+            self._counts = np.zeros((self.num_envs, max(1, eng.n_entry)), np.int32)
+        elif spawn == 'periodic':
+            eng.set_spawns(period=spawn_period)
+        elif spawn in (None, 'none'):
+            eng.set_spawns()
+        else:
+            raise ValueError("spawn must be poisson|regular|periodic|none")
+        self._phase_rng = np.random.RandomState(seed + 7919 + self.env_id_offset)
+        self.obs, self.rewards, self.done = eng.obs, eng.rewards, eng.done
+
+    @property
+    def observation_shape(self):
+        return (self.num_envs, self.engine.obs_len)
+
+    def reset(self, phase_init=None):
+        eng = self.engine
+        if phase_init is None:
+            phase_init = self._phase_rng.randint(2, size=(eng.E, eng.I)).astype(np.int32)
+        eng.reset(phase_init)
+        return eng.obs
+
+    def step(self, actions=None, n_ticks=1, cycle_period=None):
+        """actions: int tensor [E, I] on the device (held for n_ticks, like the Repeater wrapper,
+        traffic_test.py:48-49) or None with cycle_period for the on-device fixed-cycle controller.
+        Returns live device tensors (obs int32 [E,2r+2I], rewards f32 [E,I], done u8 [E])."""
+        eng = self.engine
+        if cycle_period is not None:
+            eng.set_actions(cycle_period=cycle_period)
+        elif actions is not None:
+            eng.set_actions(actions)
+        if self.spawn in ('poisson', 'regular'):
+            for _ in range(int(n_ticks)):
+                for k, s in enumerate(self._sched):
+                    counts_from_roads(s.next_tick(), eng.entry_index, eng.n_entry, out=self._counts[k])
+                eng.set_spawns(counts=self._counts)
+                eng.step(1)
+        else:
+            eng.step(int(n_ticks))
+        return eng.obs, eng.rewards, eng.done
+
+    def remi_reward(self):
+        return self.engine.remi_reward()
+
+    def cars_on_roads(self):
+        return self.engine.cars_on_roads()

@@ -1,0 +1,79 @@
+"""Host-side car arrival schedules.
+
+`SpawnSchedule` replays, call for call on a legacy `numpy.random.RandomState`, the two car
+generators of the reference and the entry-road draw of `add_new_cars` (traffic_env.py:160-176 and
+:274-283), so that `seed_generator(seed)` yields the same (tick, road) sequence as the reference -
+"identical seeds/spawns".  RNG draws per car, in order: `exponential` (gap to the next car, Poisson
+only), `randint(n_archetypes)`, `choice(entrypoints)`.  The device only ever sees per-tick counts.
+"""
+import math
+
+import numpy as np
+
+
+class SpawnSchedule(object):
+    def __init__(self, rand, poisson, entrypoints, rate_fn, n_archetypes=1):
+        """rate_fn() -> (cars_per_sec, rate) is read lazily at the first tick, like the reference's
+        generators read FLAGS when first advanced (reset_entrypoints sets cars_per_sec after
+        seed_generator in make_env, traffic_test.py:81-82)."""
+        self.rand = rand
+        self.poisson = bool(poisson)
+        self.entrypoints = entrypoints
+        self.rate_fn = rate_fn
+        self.n_archetypes = int(n_archetypes)
+        self._started = False
+        self._gap = None      # whole ticks left before the next Poisson car; None = draw a new gap
+        self._i = 0           # tick counter of the regular generator
+
+    def _start(self):
+        cps, rate = self.rate_fn()
+        per_tick = cps * rate
+        if self.poisson:
+            self._mean_gap = 1 / per_tick
+        else:
+            self._every = round(1 / per_tick)
+            self._burst = math.ceil(per_tick)
+        self._started = True
+
+    def _poisson_tick(self):
+        n = 0
+        while True:
+            if self._gap is None:
+                self._gap = round(self.rand.exponential(self._mean_gap))
+            if self._gap > 0:
+                self._gap -= 1
+                return n
+            self.rand.randint(self.n_archetypes)   # archetype pick (one archetype: always 0)
+            self._gap = None
+            n += 1
+            yield_road = self.rand.choice(self.entrypoints)
+            self._roads.append(int(yield_road))
+
+    def _regular_tick(self):
+        due = self._every == 0 or self._i % self._every == 0
+        self._i += 1
+        if due:
+            for _ in range(self._burst):
+                self._roads.append(int(self.rand.choice(self.entrypoints)))
+
+    def next_tick(self):
+        """Entry roads of the cars created this tick, in creation order."""
+        if not self._started:
+            self._start()
+        self._roads = []
+        if self.poisson:
+            self._poisson_tick()
+        else:
+            self._regular_tick()
+        return self._roads
+
+
+def counts_from_roads(roads, entry_index, n_entry, out=None):
+    """int32[n_entry] cars per entry road for one tick (cars are identical: only counts matter)."""
+    if out is None:
+        out = np.zeros(n_entry, np.int32)
+    else:
+        out[:] = 0
+    for rd in roads:
+        out[entry_index[rd]] += 1
+    return out

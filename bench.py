@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: vehicle-updates/s of the IDM traffic-env tick on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one env tick (TrafficEnv._step, reference traffic_env.py:224-248) over EVERY env of
+the batch: the move kernel + the advance kernel.  Workload = BASELINE.json's headline single-GPU
+configuration (cfg2: 4096 envs/GPU, 16x16 grid, 64-car roads) on synthetic fixed-spawn traffic
+generated on the device (gym_traffic/workload.py); per-GPU work is fixed as N grows (weak scaling),
+envs are sharded by id with no collective in the step; for N > 1 a snapshot of (obs, reward, done)
+is gathered to rank 0 over RCCL every 10 ticks on a side stream (cfg3).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel (k_move): algorithmic bytes per launch / its mean duration measured
+                with HIP events on the launch stream inside the timed region, against 8 TB/s;
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/idm_oracle.c) timed on
+                this host's cores on a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "traffic-env_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+GATHER_EVERY = 10           # ticks between (obs, reward, done) snapshots to rank 0 (one agent step)
+
+
+def cpu_baseline(name, budget_s=12.0, max_ticks=60):
+    """Time the oracle on a bounded sample of the same workload: envs = 2 per host thread (at most
+    64), same prefill / spawn / light rules, until `budget_s` seconds or `max_ticks` ticks."""
+    import numpy as np
+    from gym_traffic import workload as wl
+    from oracle.oracle import OracleEnv, ARCHETYPE, live_mask
+    from gym_traffic.envs.roadgraph import GridRoad
+
+    c = wl.CONFIGS[name]
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    envs = max(1, min(64, 2 * threads, c["envs"]))
+    g = GridRoad(c["m"], c["n"], c["length"])
+    g.generate_entrypoints(0)
+    orc = OracleEnv(c["m"], c["n"], c["length"], c["capacity"], g.dest, g.phases, g.nexts, n_envs=envs)
+    orc.reset(np.zeros(orc.I, np.int32))
+    x, v, leading, lastcar = wl.prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
+    w = np.zeros_like(x)
+    for k in range(envs):
+        orc.load_planes(k, x, v, w, leading, lastcar)
+    env_ids = np.arange(envs)
+    sched = []
+    for t in range(max_ticks):
+        roads = np.asarray(wl.spawn_roads_for_tick(g.entrypoints, t), np.int32)
+        off = np.arange(envs + 1, dtype=np.int64) * len(roads)
+        sched.append((wl.cycle_actions(env_ids, orc.I, t), (off, np.tile(roads, envs))))
+    orc.step(*sched[0], nthreads=threads)            # warm the code and the caches
+    base = orc.vehicle_updates
+    t0 = time.perf_counter()
+    ticks = 0
+    for t in range(1, max_ticks):
+        orc.step(*sched[t], nthreads=threads)
+        ticks += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    updates = orc.vehicle_updates - base
+    return {"value": updates / dt, "unit": "vehicle-updates/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d ticks of %s (%.3g vehicle-updates in %.1f s), OpenMP over envs, "
+                      "oracle/idm_oracle.c" % (envs, ticks, name, updates, dt)}
+
+
+def load_pmc_traffic(name):
+    """Per-launch HBM bytes of k_move from the committed rocprofv3 PMC summary, if one exists for
+    this workload (profiles/pmc_<cfg>.json, written by tools/pmc_summary.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
+    try:
+        with open(path) as f:
+            return json.load(f).get("k_move_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    from gym_traffic import workload as wl
+    from gym_traffic.distributed import RolloutGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    c = wl.CONFIGS[a.config]
+    E = int(a.envs if a.envs is not None else c["envs"])
+    eng = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
+    gather = None
+    if world > 1 and not a.no_gather:
+        gather = RolloutGather(E, eng.obs_len, eng.I, device)
+
+    def run(n):
+        done = 0
+        while done < n:
+            k = min(GATHER_EVERY, n - done) if gather is not None else n - done
+            eng.step(k)
+            done += k
+            if gather is not None and done % GATHER_EVERY == 0:
+                gather.start(eng.obs, eng.rewards, eng.done)
+        if gather is not None:
+            gather.wait()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(a.warmup)
+    eng.reset_counters()
+    eng.profile(a.steps)
+    fence()
+    t0 = time.perf_counter()
+    run(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+
+    updates = eng.vehicle_updates()
+    prof = eng.profile_read()
+    eng.profile(0)
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    uu = torch.tensor([updates], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+    dt_max, total_updates = float(tt.item()), float(uu.item())
+
+    if rank == 0:
+        K = a.steps
+        live_per_tick = updates / K                                   # rank 0's mean live cars / tick
+        move_ms = prof["move_ms"] / max(1, prof["ticks"])
+        adv_ms = prof["advance_ms"] / max(1, prof["ticks"])
+        # algorithmic bytes: 16 B per vehicle-update + 48 B per road-tick go to
+        # k_move (it reads/writes every car and the per-road words); the 32 B per
+        # intersection-tick belong to k_advance.  See DESIGN.md "Roofline accounting".
+        move_bytes = 16.0 * live_per_tick + 48.0 * E * eng.R
+        tick_bytes = wl.algorithmic_bytes_per_tick(live_per_tick, E * eng.R, E * eng.I)
+        achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
+        out = {
+            "metric": "vehicle_updates_per_sec",
+            "value": total_updates / dt_max,
+            "unit": "vehicle-updates/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": a.warmup,
+            "ms_per_step": dt_max / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.describe(a.config), "envs_per_gpu": E,
+                       "grid": "%dx%d" % (c["m"], c["n"]), "cars_per_road_max": c["capacity"] - 2,
+                       "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of obs/reward/done "
+                                                             "to rank 0 every %d ticks" % GATHER_EVERY
+                                                             if gather is not None else "")},
+            "env_steps_per_sec": world * E * K / dt_max,
+            "mean_live_cars_per_road": live_per_tick / (E * eng.R),
+            "roofline": {"bound": "hbm", "kernel": "k_move", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_pmc_traffic(a.config) if E == c["envs"] else None,
+                         "algorithmic_bytes_per_launch": move_bytes, "launch_ms": move_ms,
+                         "launches_timed": prof["ticks"], "k_advance_ms": adv_ms,
+                         "tick_algorithmic_bytes": tick_bytes,
+                         "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                         if move_ms + adv_ms > 0 else 0.0},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.config)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,9 @@ typedef struct tfx_config {
   int32_t learn_switch;  /* FLAGS.learn_switch (traffic_env.py:15,225-230) */
   int32_t validate;      /* FLAGS.mode == 'validate': advance_hack records trip times (traffic_env.py:240-242) */
   uint32_t entry_spec;   /* generate_entrypoints(spec) bit mask (roadgraph.py:42-51) */
+  int32_t env_id_offset; /* global id of env 0 of this handle (env-sharded multi-GPU runs): the
+                            on-device controllers use env + offset, so results do not depend on the
+                            sharding */
 } tfx_config;
 
 typedef struct tfx_buffers {
@@ -148,6 +151,11 @@ int tfx_set_tick(tfx_handle h, int32_t tick);               /* also clears the p
 /* live cars advanced by move_cars since the last tfx_reset_counters (synchronises the stream) */
 int tfx_vehicle_updates(tfx_handle h, uint64_t *out, void *stream);
 int tfx_reset_counters(tfx_handle h, void *stream);
+/* Per-kernel timing for the roofline report: with max_ticks > 0 the next tfx_step calls record HIP
+ * events on the launch stream around the move and advance kernels of up to max_ticks ticks;
+ * tfx_profile_read waits for them and returns (and clears) the summed durations. 0 disables. */
+int tfx_profile(tfx_handle h, int32_t max_ticks);
+int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t *n_ticks);
 /* launch geometry of the move kernel, for the roofline report */
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
 

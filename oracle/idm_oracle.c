@@ -135,17 +135,20 @@ static void update_lights(const orc_cfg *c, const int32_t *dests, const int32_t 
   }
 }
 
-/* traffic_env.py:187-212  move_cars */
-void orc_move_cars(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
-                   const int32_t *nexts, orc_env *v) {
+/* traffic_env.py:187-212  move_cars.  Returns the number of live cars advanced (the
+ * "vehicle-updates" of this tick; bookkeeping for the benchmark, not part of the reference). */
+int64_t orc_move_cars(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
+                      const int32_t *nexts, orc_env *v) {
   const int C = c->C;
   float nx[C + 1], nv[C + 1];
   int32_t *detected = v->obs + c->r;
   const float near_end = c->length - c->detect_dist;
+  int64_t updates = 0;
   update_lights(c, dests, phases, nexts, v);
   for (int e = 0; e < c->R; ++e) {
     const int ld = v->leading[e], lc = v->lastcar[e];
     if (ld == lc) continue;
+    updates += lc - ld + (ld > lc ? C - 1 : 0);
     if (ld < lc) {
       sim(c, v, e, ld, lc, nx, nv);
       if (dests[e] >= 0) {
@@ -177,6 +180,7 @@ void orc_move_cars(const orc_cfg *c, const int32_t *dests, const int32_t *phases
       }
     }
   }
+  return updates;
 }
 
 /* traffic_env.py:97-114  add_car; `car` is a 10-vector */
@@ -274,7 +278,7 @@ void orc_reset(const orc_cfg *c, orc_env *v, const int32_t *phase_init) {
  */
 int orc_step(const orc_cfg *c, const int32_t *dests, const int32_t *phases, const int32_t *nexts,
              orc_env *v, const int32_t *action, const int32_t *spawn_roads, int n_spawn,
-             float tick, float *trip_times, int64_t *n_trips, int64_t trip_cap) {
+             float tick, float *trip_times, int64_t *n_trips, int64_t trip_cap, int64_t *updates) {
   int32_t *passed = v->obs, *cur = v->obs + 2 * c->r, *elapsed = cur + c->I;
   for (int i = 0; i < c->I; ++i) {
     int change;
@@ -297,7 +301,8 @@ int orc_step(const orc_cfg *c, const int32_t *dests, const int32_t *phases, cons
     car[WI] = tick;
     overflowed = add_car(c, spawn_roads[k], car, v, dests) || overflowed;
   }
-  orc_move_cars(c, dests, phases, nexts, v);
+  const int64_t u = orc_move_cars(c, dests, phases, nexts, v);
+  if (updates) *updates += u;
   overflowed = orc_advance(c, dests, nexts, v, tick, trip_times, n_trips, trip_cap) || overflowed;
   return overflowed;
 }
@@ -333,17 +338,22 @@ void orc_reset_batch(const orc_cfg *c, const orc_bufs *b, const int32_t *phase_i
 void orc_step_batch(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
                     const int32_t *nexts, const orc_bufs *b, const int32_t *action,
                     const int64_t *spawn_off, const int32_t *spawn_roads, const float *ticks,
-                    float *trip_times, int64_t *n_trips, int64_t trip_cap, int nthreads) {
+                    float *trip_times, int64_t *n_trips, int64_t trip_cap, int nthreads,
+                    int64_t *updates) {
+  int64_t total = 0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : total)
 #endif
   for (int k = 0; k < c->E; ++k) {
     orc_env v = env_view(c, b, k);
+    int64_t u = 0;
     b->done[k] = (uint8_t)orc_step(c, dests, phases, nexts, &v, action + (size_t)k * c->I,
                                    spawn_roads + spawn_off[k], (int)(spawn_off[k + 1] - spawn_off[k]),
                                    ticks[k], trip_times ? trip_times + (size_t)k * trip_cap : NULL,
-                                   n_trips ? n_trips + k : NULL, trip_cap);
+                                   n_trips ? n_trips + k : NULL, trip_cap, &u);
+    total += u;
   }
+  if (updates) *updates += total;
   (void)nthreads;
 }
 

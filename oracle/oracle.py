@@ -112,6 +112,7 @@ class OracleEnv(object):
         self.trip_cap = int(trip_cap)
         self.trip_times = np.zeros((E, self.trip_cap), np.float32)
         self.n_trips = np.zeros(E, np.int64)
+        self._updates = C.c_int64(0)   # live cars advanced by move_cars so far (benchmark bookkeeping)
         b = OrcBufs()
         for k in ("state", "leading", "lastcar", "obs", "rewards", "waiting", "passed_dst", "done"):
             setattr(b, k, _p(getattr(self, k)))
@@ -176,9 +177,13 @@ class OracleEnv(object):
         lib().orc_step_batch(C.byref(self.cfg), _p(self.dest), _p(self.phases), _p(self.nexts),
                              C.byref(self.bufs), _p(act), _p(off), _p(roads), _p(self.steps),
                              _p(self.trip_times), _p(self.n_trips), C.c_int64(self.trip_cap),
-                             C.c_int(int(nthreads)))
+                             C.c_int(int(nthreads)), C.byref(self._updates))
         self.steps += np.float32(1)
         return self.obs, self.rewards, self.done
+
+    @property
+    def vehicle_updates(self):
+        return int(self._updates.value)
 
     def move_cars(self):
         lib().orc_move_cars_batch(C.byref(self.cfg), _p(self.dest), _p(self.phases), _p(self.nexts),

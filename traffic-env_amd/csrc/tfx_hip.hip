@@ -60,7 +60,7 @@ int fail(int code, const char *fmt, ...) {
 // Everything a kernel needs, passed by value.
 struct Dev {
   int I, r, R, C, E, P, n_entry, obs_len;
-  int yellow, learn_switch, validate;
+  int yellow, learn_switch, validate, env_off;
   float length, rate, car_v, car_l, car_a, car_v0, car_b, car_T, car_s0;
   float two_sab, eps, thresh, near_end, ovf_pen;
   // caller-owned state
@@ -114,7 +114,7 @@ __device__ __forceinline__ void light_update(const Dev &d, int env, int i, int t
   const int ph = ob[i], el = ob[d.I + i];
   int a;
   if (d.action_mode == TFX_ACTION_CYCLE)
-    a = ((tick + env % d.action_period) / d.action_period) & 1;
+    a = ((tick + (env + d.env_off) % d.action_period) / d.action_period) & 1;
   else if (d.action_mode == TFX_ACTION_BROADCAST)
     a = d.action[(size_t)tidx * d.action_stride + i];
   else
@@ -631,6 +631,10 @@ struct tfx_handle_s {
   int *dev_tables = nullptr;  // nexts | pred | entry_idx
   void *dev_scratch = nullptr;
   int32_t action_per_tick = 0, spawn_per_tick = 0;
+  // optional per-kernel timing with HIP events on the launch stream (tfx_profile)
+  std::vector<hipEvent_t> ev;
+  int ev_ticks = 0, ev_used = 0;
+  bool prof = false;
 };
 
 namespace {
@@ -747,6 +751,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.yellow = cfg->yellow_ticks;
   d.learn_switch = cfg->learn_switch;
   d.validate = cfg->validate;
+  d.env_off = cfg->env_id_offset;
   d.length = cfg->length;
   d.rate = cfg->rate;
   d.car_v = cfg->car_v; d.car_l = cfg->car_l; d.car_a = cfg->car_a; d.car_v0 = cfg->car_v0;
@@ -820,6 +825,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
 
 int tfx_destroy(tfx_handle h) {
   if (!h) return TFX_OK;
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
   if (h->dev_scratch) (void)hipFree(h->dev_scratch);
   delete h;
@@ -922,8 +928,16 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   if (n_ticks < 0) return fail(TFX_EINVAL, "n_ticks < 0");
   hipStream_t st = (hipStream_t)stream;
   for (int t = 0; t < n_ticks; ++t) {
+    const bool timed = h->prof && h->ev_used < h->ev_ticks;
+    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(e[0], st));
     if (int rc = launch_move(h, t, st)) return rc;
+    if (timed) HIPCHK(hipEventRecord(e[1], st));
     if (int rc = launch_advance(h, t, st)) return rc;
+    if (timed) {
+      HIPCHK(hipEventRecord(e[2], st));
+      ++h->ev_used;
+    }
   }
   return TFX_OK;
 }
@@ -996,6 +1010,38 @@ int tfx_vehicle_updates(tfx_handle h, uint64_t *out, void *stream) {
 int tfx_reset_counters(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, false)) return rc;
   HIPCHK(hipMemsetAsync(h->d.veh, 0, sizeof(unsigned long long), (hipStream_t)stream));
+  return TFX_OK;
+}
+
+int tfx_profile(tfx_handle h, int32_t max_ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  h->ev.clear();
+  h->ev_ticks = 0;
+  h->ev_used = 0;
+  h->prof = max_ticks > 0;
+  if (!h->prof) return TFX_OK;
+  h->ev.resize((size_t)max_ticks * 3);
+  for (hipEvent_t &e : h->ev) HIPCHK(hipEventCreate(&e));
+  h->ev_ticks = max_ticks;
+  return TFX_OK;
+}
+
+int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t *n_ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  double mv = 0.0, ad = 0.0;
+  for (int i = 0; i < h->ev_used; ++i) {
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventSynchronize(h->ev[(size_t)i * 3 + 2]));
+    HIPCHK(hipEventElapsedTime(&a, h->ev[(size_t)i * 3], h->ev[(size_t)i * 3 + 1]));
+    HIPCHK(hipEventElapsedTime(&b, h->ev[(size_t)i * 3 + 1], h->ev[(size_t)i * 3 + 2]));
+    mv += a;
+    ad += b;
+  }
+  if (move_ms) *move_ms = mv;
+  if (advance_ms) *advance_ms = ad;
+  if (n_ticks) *n_ticks = h->ev_used;
+  h->ev_used = 0;
   return TFX_OK;
 }
 

@@ -19,7 +19,8 @@ class TfxConfig(C.Structure):
                 ("car_T", C.c_float), ("car_s0", C.c_float),
                 ("yellow_ticks", C.c_int32), ("thresh", C.c_float), ("detect_dist", C.c_float),
                 ("overflow_penalty", C.c_float), ("eps", C.c_float),
-                ("learn_switch", C.c_int32), ("validate", C.c_int32), ("entry_spec", C.c_uint32)]
+                ("learn_switch", C.c_int32), ("validate", C.c_int32), ("entry_spec", C.c_uint32),
+                ("env_id_offset", C.c_int32)]
 
 
 class TfxBuffers(C.Structure):
@@ -57,6 +58,8 @@ _PROTOS = {
     "tfx_set_tick": (C.c_int, [C.c_void_p, C.c_int32]),
     "tfx_vehicle_updates": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "tfx_reset_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tfx_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "tfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "tfx_launch_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 3),
 }
 

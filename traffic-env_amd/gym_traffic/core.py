@@ -29,7 +29,7 @@ def _ptr(t):
 
 class TfxEngine(object):
     def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
-                 validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None):
+                 validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0):
         if not torch.cuda.is_available():
             raise nat.TfxError("no GPU visible: the traffic env step runs on MI355X only (no CPU fallback)")
         self.lib = nat.lib()
@@ -45,6 +45,7 @@ class TfxEngine(object):
             setattr(cfg, k, v)
         cfg.learn_switch, cfg.validate = int(bool(learn_switch)), int(bool(validate))
         cfg.entry_spec = int(entry_spec)
+        cfg.env_id_offset = int(env_id_offset)
         self.cfg = cfg
         self.validate = bool(validate)
         h = C.c_void_p()
@@ -111,7 +112,7 @@ class TfxEngine(object):
     # ---- the reference's operations ----------------------------------------------------------
     def reset(self, phase_init):
         """TrafficEnv._reset (traffic_env.py:259-272); phase_init int[E,I] or [I]."""
-        ph = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(
+        ph = torch.as_tensor(np.array(np.broadcast_to(
             np.asarray(phase_init, np.int32), (self.E, self.I)))).to(self.device)
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_reset(self.h, _ptr(ph), self._stream()))
@@ -198,6 +199,15 @@ class TfxEngine(object):
 
     def reset_counters(self):
         nat.check(self.lib.tfx_reset_counters(self.h, self._stream()))
+
+    def profile(self, max_ticks):
+        """Record HIP events around the kernels of the next `max_ticks` ticks (0 = off)."""
+        nat.check(self.lib.tfx_profile(self.h, int(max_ticks)))
+
+    def profile_read(self):
+        mv, ad, n = C.c_double(), C.c_double(), C.c_int32()
+        nat.check(self.lib.tfx_profile_read(self.h, C.byref(mv), C.byref(ad), C.byref(n)))
+        return dict(move_ms=mv.value, advance_ms=ad.value, ticks=n.value)
 
     def launch_info(self):
         v = [C.c_int32() for _ in range(3)]

@@ -24,7 +24,7 @@ class TrafficVecEnv(object):
         self.graph.generate_entrypoints(entry_spec)
         self.engine = TfxEngine(m, n, length, capacity, n_envs=num_envs, rate=rate,
                                 learn_switch=learn_switch, validate=validate,
-                                entry_spec=entry_spec, device=device)
+                                entry_spec=entry_spec, device=device, env_id_offset=env_id_offset)
         self.rate = float(rate)
         open_sides = 4 - bin(int(entry_spec) & 15).count('1')
         self.cars_per_sec = local_cars_per_sec * m * open_sides

@@ -30,6 +30,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -361,6 +362,256 @@ __global__ __launch_bounds__(256) void k_move(const Dev d, const int tidx) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_move_tile: the C-2 <= 64 form of k_move (one wavefront per road), restructured so that a wave
+// owns a TILE of 64 consecutive roads and works in three wave-local phases - no block barrier:
+//   M  lane j prepares road j of the tile: ring indices, light state, fake-leader x, spawns.  All
+//      per-road scalar work (index arithmetic, table/obs gathers, the next road's tail) is done
+//      64 roads at a time with coalesced loads instead of once per road with wave-uniform loads.
+//   C  for each road of the tile, all 64 lanes take one car each: coalesced x/v loads, LDS leader
+//      staging, IDM, coalesced stores, ballot counts.  Loads of the next group of U roads are
+//      issued before the current group is computed, so 2*U roads are in flight per wave.
+//   W  lane j writes road j's results (waiting/detected/passed, the handoff record) coalesced.
+// Descriptors and results travel through LDS entries that only this wave touches.
+// ------------------------------------------------------------------------------------------------
+struct RoadDesc {
+  int ld, lc, n_old, n_tot;
+  float xL, xs0;
+  int ovf_sp, pad;
+};
+
+struct CarRegs {
+  float x, v;
+  int slot;
+};
+
+__device__ __forceinline__ void tile_load(const Dev &d, const RoadDesc &sd, int id, int lane, CarRegs &c) {
+  const int C = d.C;
+  const float *xs = d.state + ((size_t)id * d.P) * C;
+  c.slot = ring_adv(sd.ld, 1 + lane, C);
+  c.x = 0.0f;
+  c.v = 0.0f;
+  if (lane < sd.n_old) {
+    c.x = xs[c.slot];
+    c.v = xs[C + c.slot];
+  } else if (lane < sd.n_tot) {
+    // car spawned this tick: the j-th accepted spawn queues behind the (j-1)-th (add_car :100-107)
+    float xv = sd.xs0;
+    for (int j = sd.n_old; j < lane; ++j) xv = (xv - d.car_l) - d.car_s0;
+    c.x = xv;
+    c.v = d.car_v;
+  }
+}
+
+__device__ __forceinline__ void tile_compute(const Dev &d, const RoadDesc &sd, int id, int lane, int tick,
+                                             float *sx, float *sv, int4 *res, const CarRegs &c) {
+  const int C = d.C;
+  float *xs = d.state + ((size_t)id * d.P) * C;
+  float *vs = xs + C;
+  float *ws = xs + 2 * C;
+  const float x = c.x, v = c.v;
+  // stage: index 0 = fake leader (v = 0, l = 0), index k+1 = car k; lane k then reads index k
+  if (lane == 0) {
+    sx[0] = sd.xL;
+    sv[0] = 0.0f;
+  }
+  sx[lane + 1] = x;
+  sv[lane + 1] = v;
+  __builtin_amdgcn_wave_barrier();
+  const float xl = sx[lane];
+  const float vl = sv[lane];
+  __builtin_amdgcn_wave_barrier();
+  const float ll = (lane == 0) ? 0.0f : d.car_l;
+
+  const float t_gap = v * d.car_T;
+  const float appr = v * (v - vl);
+  const float s_star = d.car_s0 + np_max0(t_gap + appr / d.two_sab);
+  const float s = (xl - x) - ll;
+  const float q = v / d.car_v0;
+  const float qd = pow4_cr(q);
+  const float u = s_star / (s + d.eps);
+  const float dv = d.car_a * ((1.0f - qd) - u * u);
+  const float dvr = dv * d.rate;
+  const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+  const float xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+  const float vn = np_max0(v + dvr);
+
+  const bool is_live = lane < sd.n_tot;
+  const bool is_spawned = is_live && lane >= sd.n_old;
+  if (is_live) {
+    xs[c.slot] = xn;
+    vs[c.slot] = vn;
+    if (is_spawned && d.P == 3) ws[c.slot] = (float)tick;
+  }
+  const bool seg2 = (sd.ld > sd.lc) && (c.slot <= sd.lc);
+  const bool c_wait = is_live && ((seg2 ? xn : vn) < d.thresh);
+  const bool c_det = is_live && (xn > d.near_end);
+  const bool c_pop = is_live && (xn > d.length);
+  const bool c_far = c_pop && ((xn - d.length) > d.length);
+  const unsigned long long m_pop = __ballot(c_pop);
+  const int n_wait = __popcll(__ballot(c_wait));
+  const int n_det = __popcll(__ballot(c_det));
+  const int kpop = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+  const bool slow = (kpop > KP) || (__ballot(c_far) != 0ull);
+  if (lane == 0) {
+    res->x = kpop | (slow ? (1 << 30) : 0);
+    res->y = n_wait;
+    res->z = n_det;
+  }
+  if (is_live && lane == sd.n_tot - 1) res->w = __float_as_int(xn);
+  if (is_live && lane < kpop && lane < KP) {
+    float w = 0.0f;
+    if (d.P == 3) w = is_spawned ? (float)tick : ws[c.slot];
+    float *pc = d.popcar + ((size_t)id * KP + lane) * 3;
+    pc[0] = xn;
+    pc[1] = vn;
+    pc[2] = w;
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_move_tile(const Dev d, const int tidx) {
+  constexpr int TR = 64;  // roads per wave tile
+  __shared__ RoadDesc s_desc[4][TR];
+  __shared__ int4 s_res[4][TR];
+  __shared__ float s_x[4][TR + 2];
+  __shared__ float s_v[4][TR + 2];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tick = *d.tickA;
+  const int C = d.C;
+  RoadDesc *desc = s_desc[wv];
+  int4 *res = s_res[wv];
+  float *sx = s_x[wv], *sv = s_v[wv];
+
+  // waves take contiguous runs of tiles; blocks b and b+8 share an XCD, so XCD x gets the x-th
+  // eighth of all tiles (neighbouring roads -> one L2).  Speed only.
+  const int G = gridDim.x;
+  const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const long total = (long)d.E * d.R;
+  const long tiles = (total + TR - 1) / TR;
+  const long nw = (long)G * 4;
+  const long chunk = (tiles + nw - 1) / nw;
+  const long t0 = ((long)lb * 4 + wv) * chunk;
+  const long t1 = (t0 + chunk < tiles) ? t0 + chunk : tiles;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = t0; tile < t1; ++tile) {
+    const long base = tile * TR;
+    // ================= phase M: lane j <-> road base + j ========================================
+    const bool valid = base + lane < total;
+    const int id = valid ? (int)(base + lane) : (int)(total - 1);
+    const int env = id / d.R;
+    const int e = id - env * d.R;
+    const bool train = e < d.r;
+    const int dir = train ? e / d.I : 0;
+    const int dst = e - dir * d.I;
+    RoadDesc rd;
+    rd.ld = d.leading[id];
+    rd.lc = d.lastcar[id];
+    rd.n_old = ring_count(rd.ld, rd.lc, C);
+    rd.n_tot = rd.n_old;
+    rd.xL = INFINITY;
+    rd.xs0 = 0.0f;
+    rd.ovf_sp = 0;
+    rd.pad = 0;
+    if (train) {
+      int ph_new, el_new;
+      light_update(d, env, dst, tick, tidx, ph_new, el_new);
+      const int phase_e = (dir < 2) ? 1 : 0;
+      if (phase_e == ph_new || el_new < d.yellow) {
+        rd.xL = d.length;
+      } else {
+        const int idn = env * d.R + d.nexts[e];
+        if (d.lastcar[idn] != d.leading[idn]) rd.xL = d.tailx[idn] + d.length;
+      }
+    }
+    const int ej = d.entry_idx[e];
+    if (ej >= 0 && valid) {
+      int c;
+      if (d.spawn_mode == TFX_SPAWN_COUNTS)
+        c = d.spawn[(size_t)tidx * d.spawn_stride + (size_t)env * d.n_entry + ej];
+      else if (d.spawn_mode == TFX_SPAWN_PERIODIC)
+        c = (tick_sp == e % d.spawn_period) ? 1 : 0;
+      else
+        c = 0;
+      if (c > 0) {
+        float tail_x = d.tailx[id];
+        for (int j = 0; j < c; ++j) {
+          const int pos = wrap1(rd.lc + 1, C);
+          const float start = (rd.lc != rd.ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+          if (pos != rd.ld) {
+            const float xv = (start < 0.0f) ? start : 0.0f;
+            if (rd.n_tot == rd.n_old) rd.xs0 = xv;
+            ++rd.n_tot;
+            rd.lc = pos;
+            tail_x = xv;
+          } else {
+            ++rd.ovf_sp;
+          }
+        }
+        if (rd.n_tot != rd.n_old) d.lastcar[id] = rd.lc;
+      }
+    }
+    if (valid) d.state[((size_t)id * d.P) * C + rd.ld] = rd.xL;  // the leader's x stays in its slot
+    desc[lane] = rd;
+    __builtin_amdgcn_wave_barrier();
+
+    // ================= phase C: all lanes on one road at a time ==================================
+    const long left = total - base;
+    const int nroads = left < TR ? (int)left : TR;
+    const int idb = (int)base;
+    CarRegs ra[U], rb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < nroads) tile_load(d, desc[u], idb + u, lane, ra[u]);
+    for (int g = 0; g < nroads; g += 2 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + U + u < nroads) tile_load(d, desc[g + U + u], idb + g + U + u, lane, rb[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + u < nroads) tile_compute(d, desc[g + u], idb + g + u, lane, tick, sx, sv, &res[g + u], ra[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + 2 * U + u < nroads) tile_load(d, desc[g + 2 * U + u], idb + g + 2 * U + u, lane, ra[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + U + u < nroads)
+          tile_compute(d, desc[g + U + u], idb + g + U + u, lane, tick, sx, sv, &res[g + U + u], rb[u]);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ================= phase W: lane j writes road j's results ===================================
+    if (valid) {
+      const int4 rs = res[lane];
+      const int kpop = rs.x & 0xffff;
+      const bool slow = (rs.x >> 30) & 1;
+      if (train) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (rd.n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += rs.y;
+          ob[d.r + e] = rs.z;
+        }
+        ob[e] = kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + dst] = 1;
+      }
+      d.rec[id] = make_int4(kpop, rd.ovf_sp, rs.w, rd.n_tot);
+      if (slow) d.env_flag[env] = tick + 1;
+      my_updates += (unsigned long long)rd.n_tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ring pop + handoff for destination road e, pull form.  Returns the overflow count of pushes
 // into e.  Exact restatement of what the reference's sequential loop (advance_finished_cars
 // :117-135) does to road e, given that (a) e's own pops are its first k_e cars and (b) the cars
@@ -635,6 +886,7 @@ struct tfx_handle_s {
   std::vector<hipEvent_t> ev;
   int ev_ticks = 0, ev_used = 0;
   bool prof = false;
+  int move_variant = 0;  // 0: k_move_tile<2> (default); 4: k_move_tile<4>; 1: k_move<1> (TFX_MOVE_VARIANT, A/B runs)
 };
 
 namespace {
@@ -682,10 +934,44 @@ int check_handle(tfx_handle h, bool need_bound) {
   return TFX_OK;
 }
 
+// Grid of the move kernel: every block resident at once (occupancy query), a multiple of 8 so the
+// XCD-contiguous chunking applies, never more blocks than there is work.
+template <typename K>
+int move_grid(tfx_handle h, K kernel, long work_items_per_block) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  if (per_cu > 8) per_cu = 8;
+  const long total = (long)h->d.E * h->d.R;
+  const long need = (total + work_items_per_block - 1) / work_items_per_block;
+  long g = (long)h->n_cu * per_cu;
+  if (g > need) g = need;
+  if (g >= 8) g -= g % 8;
+  return (int)(g < 1 ? 1 : g);
+}
+
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   const Dev &d = h->d;
+  if (h->grid_move == 0) {
+    switch (h->wpr) {
+      case 1:
+        h->grid_move = h->move_variant == 0   ? move_grid(h, k_move_tile<2>, 256)
+                       : h->move_variant == 4 ? move_grid(h, k_move_tile<4>, 256)
+                                              : move_grid(h, k_move<1>, 4);
+        break;
+      case 2: h->grid_move = move_grid(h, k_move<2>, 2); break;
+      default: h->grid_move = move_grid(h, k_move<4>, 1); break;
+    }
+  }
   switch (h->wpr) {
-    case 1: hipLaunchKernelGGL(k_move<1>, dim3(h->grid_move), dim3(256), 0, st, d, tidx); break;
+    case 1:
+      if (h->move_variant == 0)
+        hipLaunchKernelGGL(k_move_tile<2>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
+      else if (h->move_variant == 4)
+        hipLaunchKernelGGL(k_move_tile<4>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
+      else
+        hipLaunchKernelGGL(k_move<1>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
+      break;
     case 2: hipLaunchKernelGGL(k_move<2>, dim3(h->grid_move), dim3(256), 0, st, d, tidx); break;
     default: hipLaunchKernelGGL(k_move<4>, dim3(h->grid_move), dim3(256), 0, st, d, tidx); break;
   }
@@ -733,6 +1019,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (!h) return fail(TFX_ENOMEM, "out of host memory");
   h->cfg = *cfg;
   build_tables(h);
+  if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -765,11 +1052,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
 
   const int cars = d.C - 2;
   h->wpr = cars <= 64 ? 1 : (cars <= 128 ? 2 : 4);
-  const int rpb = 256 / (64 * h->wpr);
-  const long groups = ((long)d.E * d.R + rpb - 1) / rpb;
-  long g = groups < (long)h->n_cu * 8 ? groups : (long)h->n_cu * 8;
-  if (g >= 8) g -= g % 8;  // multiple of 8 for the XCD-contiguous chunking
-  h->grid_move = (int)(g < 1 ? 1 : g);
+  h->grid_move = 0;  // sized at the first launch from the kernel's occupancy
 
   // tables
   const size_t R = (size_t)d.R;
@@ -1047,6 +1330,7 @@ int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t 
 
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road) {
   if (int rc = check_handle(h, false)) return rc;
+  if (h->grid_move == 0) return fail(TFX_ESTATE, "no move kernel has been launched yet");
   if (grid) *grid = h->grid_move;
   if (block) *block = 256;
   if (waves_per_road) *waves_per_road = h->wpr;

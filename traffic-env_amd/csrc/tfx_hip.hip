@@ -612,6 +612,515 @@ __global__ __launch_bounds__(256) void k_move_tile(const Dev d, const int tidx) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_move_w64: k_move_tile with the per-road scalars kept out of memory altogether.
+//   * the lane that prepared road j in phase M keeps its descriptor in registers; phase C fetches
+//     it with v_readlane (-> SGPRs), so ring indices, car counts and the leader's x are scalar
+//     values, every branch on them is wave-uniform, and no descriptor LDS traffic remains;
+//   * results go the other way: lane j picks up road j's ballot counts with a select;
+//   * car addresses are a uniform tile base (SGPR pair) + a 32-bit lane offset;
+//   * the leader's (x, v) reach the follower either through the LDS tile (+1 read, LEADER_LDS) or
+//     through a DPP wave shift-right-by-one that injects the fake leader into lane 0 (no LDS);
+//     bench.py A/Bs the two (TFX_MOVE_VARIANT) - the result is identical bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct CarR {
+  float x, v;
+  int off;  // float index of the car's x relative to the tile base
+};
+
+__device__ __forceinline__ int pack_desc(int ld, int lc, int n_old, int n_tot) {
+  return ld | (lc << 9) | (n_old << 18) | (n_tot << 25);
+}
+
+template <bool LEADER_LDS>
+__device__ __forceinline__ void w64_load(const Dev &d, const float *tx, int j, int pkj, int xs0_bits,
+                                         int lane, CarR &c) {
+  const int C = d.C;
+  const int ld = pkj & 511, n_old = (pkj >> 18) & 127, n_tot = (int)((unsigned)pkj >> 25);
+  int slot = ld + 1 + lane;
+  slot = (slot >= C) ? slot - (C - 1) : slot;
+  c.off = j * (d.P * C) + slot;
+  c.x = 0.0f;
+  c.v = 0.0f;
+  if (lane < n_old) {
+    c.x = tx[c.off];
+    c.v = tx[c.off + C];
+  }
+  if (n_tot != n_old) {  // wave-uniform: cars spawned on this road this tick
+    if (lane >= n_old && lane < n_tot) {
+      float xv = __int_as_float(xs0_bits);
+      for (int q = n_old; q < lane; ++q) xv = (xv - d.car_l) - d.car_s0;
+      c.x = xv;
+      c.v = d.car_v;
+    }
+  }
+}
+
+template <bool LEADER_LDS>
+__device__ __forceinline__ void w64_compute(const Dev &d, float *tx, int idb, int j, int pkj, float xL,
+                                            int lane, int tick, float *sx, float *sv, const CarR &c,
+                                            int &r_k, int &r_w, int &r_d, int &r_t) {
+  const int C = d.C;
+  const int ld = pkj & 511, lc = (pkj >> 9) & 511, n_old = (pkj >> 18) & 127;
+  const int n_tot = (int)((unsigned)pkj >> 25);
+  const float x = c.x, v = c.v;
+  float xl, vl;
+  if (LEADER_LDS) {
+    if (lane == 0) {
+      sx[0] = xL;
+      sv[0] = 0.0f;
+    }
+    sx[lane + 1] = x;
+    sv[lane + 1] = v;
+    __builtin_amdgcn_wave_barrier();
+    xl = sx[lane];
+    vl = sv[lane];
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    // wave_shr:1 - lane k receives lane k-1, lane 0 keeps `old` = the fake leader (x = xL, v = 0)
+    xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xL), __float_as_int(x), 0x138, 0xf, 0xf, false));
+    vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+  }
+  const float ll = (lane == 0) ? 0.0f : d.car_l;
+
+  const float t_gap = v * d.car_T;
+  const float appr = v * (v - vl);
+  const float s_star = d.car_s0 + np_max0(t_gap + appr / d.two_sab);
+  const float s = (xl - x) - ll;
+  const float q = v / d.car_v0;
+  const float qd = pow4_cr(q);
+  const float u = s_star / (s + d.eps);
+  const float dv = d.car_a * ((1.0f - qd) - u * u);
+  const float dvr = dv * d.rate;
+  const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+  const float xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+  const float vn = np_max0(v + dvr);
+
+  const bool is_live = lane < n_tot;
+  if (is_live) {
+    tx[c.off] = xn;
+    tx[c.off + C] = vn;
+  }
+  if (n_tot != n_old && d.P == 3) {
+    if (lane >= n_old && lane < n_tot) tx[c.off + 2 * C] = (float)tick;
+  }
+  bool c_wait;
+  if (ld > lc) {  // wrapped ring: the reference tests x, not v, on the second segment (:210)
+    const int slot = c.off - j * (d.P * C);
+    c_wait = ((slot <= lc) ? xn : vn) < d.thresh;
+  } else {
+    c_wait = vn < d.thresh;
+  }
+  const unsigned long long m_pop = __ballot(is_live && (xn > d.length));
+  const int n_wait = __popcll(__ballot(is_live && c_wait));
+  const int n_det = __popcll(__ballot(is_live && (xn > d.near_end)));
+  int kpop = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+  int tail_bits = 0;
+  if (n_tot > 0) tail_bits = __builtin_amdgcn_readlane(__float_as_int(xn), n_tot - 1);
+  if (kpop > 0) {  // wave-uniform, ~1 road-tick in 10
+    const bool far = is_live && (xn > d.length) && ((xn - d.length) > d.length);
+    const bool slow = (kpop > KP) || (__ballot(far) != 0ull);
+    if (lane < kpop && lane < KP) {
+      float w = 0.0f;
+      if (d.P == 3) w = (lane >= n_old) ? (float)tick : tx[c.off + 2 * C];
+      float *pc = d.popcar + ((size_t)(idb + j) * KP + lane) * 3;
+      pc[0] = xn;
+      pc[1] = vn;
+      pc[2] = w;
+    }
+    kpop |= slow ? (1 << 30) : 0;
+  }
+  const bool mine = lane == j;  // lane j collects road j's results
+  r_k = mine ? kpop : r_k;
+  r_w = mine ? n_wait : r_w;
+  r_d = mine ? n_det : r_d;
+  r_t = mine ? tail_bits : r_t;
+}
+
+template <int U, bool LEADER_LDS>
+__global__ __launch_bounds__(256) void k_move_w64(const Dev d, const int tidx) {
+  constexpr int TR = 64;
+  __shared__ float s_x[4][TR + 2];
+  __shared__ float s_v[4][TR + 2];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tick = *d.tickA;
+  const int C = d.C;
+  float *sx = s_x[wv], *sv = s_v[wv];
+
+  const int G = gridDim.x;
+  const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const long total = (long)d.E * d.R;
+  const long tiles = (total + TR - 1) / TR;
+  const long nw = (long)G * 4;
+  const long chunk = (tiles + nw - 1) / nw;
+  const long t0 = ((long)lb * 4 + wv) * chunk;
+  const long t1 = (t0 + chunk < tiles) ? t0 + chunk : tiles;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = t0; tile < t1; ++tile) {
+    const long base = tile * TR;
+    // ================= phase M: lane j <-> road base + j ========================================
+    const bool valid = base + lane < total;
+    const int id = valid ? (int)(base + lane) : (int)(total - 1);
+    const int env = id / d.R;
+    const int e = id - env * d.R;
+    const bool train = e < d.r;
+    const int dir = train ? e / d.I : 0;
+    const int dst = e - dir * d.I;
+    const int ld = d.leading[id];
+    int lc = d.lastcar[id];
+    const int n_old = ring_count(ld, lc, C);
+    int n_tot = n_old, ovf_sp = 0;
+    float xL = INFINITY, xs0 = 0.0f;
+    if (train) {
+      int ph_new, el_new;
+      light_update(d, env, dst, tick, tidx, ph_new, el_new);
+      const int phase_e = (dir < 2) ? 1 : 0;
+      if (phase_e == ph_new || el_new < d.yellow) {
+        xL = d.length;
+      } else {
+        const int idn = env * d.R + d.nexts[e];
+        if (d.lastcar[idn] != d.leading[idn]) xL = d.tailx[idn] + d.length;
+      }
+    }
+    const int ej = d.entry_idx[e];
+    if (ej >= 0 && valid) {
+      int c;
+      if (d.spawn_mode == TFX_SPAWN_COUNTS)
+        c = d.spawn[(size_t)tidx * d.spawn_stride + (size_t)env * d.n_entry + ej];
+      else if (d.spawn_mode == TFX_SPAWN_PERIODIC)
+        c = (tick_sp == e % d.spawn_period) ? 1 : 0;
+      else
+        c = 0;
+      if (c > 0) {
+        float tail_x = d.tailx[id];
+        for (int q = 0; q < c; ++q) {
+          const int pos = wrap1(lc + 1, C);
+          const float start = (lc != ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+          if (pos != ld) {
+            const float xv = (start < 0.0f) ? start : 0.0f;
+            if (n_tot == n_old) xs0 = xv;
+            ++n_tot;
+            lc = pos;
+            tail_x = xv;
+          } else {
+            ++ovf_sp;
+          }
+        }
+        if (n_tot != n_old) d.lastcar[id] = lc;
+      }
+    }
+    if (valid) d.state[((size_t)id * d.P) * C + ld] = xL;  // the leader's x stays in its slot
+    const int pk = pack_desc(ld, lc, n_old, n_tot);
+    const int xL_bits = __float_as_int(xL), xs0_bits = __float_as_int(xs0);
+
+    // ================= phase C: all lanes on one road at a time ==================================
+    const long left = total - base;
+    const int nroads = left < TR ? (int)left : TR;
+    const int idb = (int)base;
+    float *tx = d.state + (size_t)base * d.P * C;  // wave-uniform tile base
+    int r_k = 0, r_w = 0, r_d = 0, r_t = 0;
+    CarR ra[U], rb[U];
+#define TFX_LOAD(J, REG)                                                                          \
+  w64_load<LEADER_LDS>(d, tx, (J), __builtin_amdgcn_readlane(pk, (J)),                             \
+                       __builtin_amdgcn_readlane(xs0_bits, (J)), lane, (REG))
+#define TFX_COMPUTE(J, REG)                                                                       \
+  w64_compute<LEADER_LDS>(d, tx, idb, (J), __builtin_amdgcn_readlane(pk, (J)),                     \
+                          __int_as_float(__builtin_amdgcn_readlane(xL_bits, (J))), lane, tick, sx, \
+                          sv, (REG), r_k, r_w, r_d, r_t)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < nroads) TFX_LOAD(u, ra[u]);
+    for (int g = 0; g < nroads; g += 2 * U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + U + u < nroads) TFX_LOAD(g + U + u, rb[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + u < nroads) TFX_COMPUTE(g + u, ra[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + 2 * U + u < nroads) TFX_LOAD(g + 2 * U + u, ra[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + U + u < nroads) TFX_COMPUTE(g + U + u, rb[u]);
+    }
+#undef TFX_LOAD
+#undef TFX_COMPUTE
+
+    // ================= phase W: lane j writes road j's results ===================================
+    if (valid) {
+      const int kpop = r_k & 0xffff;
+      if (train) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += r_w;
+          ob[d.r + e] = r_d;
+        }
+        ob[e] = kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + dst] = 1;
+      }
+      d.rec[id] = make_int4(kpop, ovf_sp, r_t, n_tot);
+      if ((r_k >> 30) & 1) d.env_flag[env] = tick + 1;
+      my_updates += (unsigned long long)n_tot;
+    }
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_move_dma: the HBM-facing form of the tick.  Same three wave-local phases as k_move_w64, but
+// phase C brings the road records in with LDS-DMA (global_load_lds_dwordx4): a sub-tile of S
+// consecutive roads is one contiguous, 16-byte-aligned span of S*P*C floats, copied to LDS by
+// whole-wave instructions of 64 lanes x 16 B = 1 KiB - the widest, fully coalesced access the
+// memory system has, with no VGPR holding the bytes in flight, so each waiting wave keeps
+// S*P*C*4 bytes (4.1 KiB at C = 66) outstanding instead of two dwords per lane.  Cars are then
+// read from the LDS image by ring slot; the follower finds its leader either at the previous ring
+// slot of the image (the +1 LDS access; the fake leader's (x, v) are patched into slot `leading`)
+// or by a DPP wave shift (LEADER_LDS = false).  New x, v go back with per-lane dword stores.
+// Needs P*C % 4 == 0 (16-byte records); otherwise k_move_w64 is used.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int S, bool LEADER_LDS>
+__global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
+  constexpr int TR = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tick = *d.tickA;
+  const int C = d.C;
+  const int stride = d.P * C;                   // floats per road record
+  const int sub_floats = S * stride;            // multiple of 4
+  float *buf = reinterpret_cast<float *>(smem) + (size_t)wv * sub_floats;
+
+  const int G = gridDim.x;
+  const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const long total = (long)d.E * d.R;
+  const long tiles = (total + TR - 1) / TR;
+  const long nw = (long)G * 4;
+  const long chunk = (tiles + nw - 1) / nw;
+  const long t0 = ((long)lb * 4 + wv) * chunk;
+  const long t1 = (t0 + chunk < tiles) ? t0 + chunk : tiles;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = t0; tile < t1; ++tile) {
+    const long base = tile * TR;
+    // ================= phase M: lane j <-> road base + j ========================================
+    const bool valid = base + lane < total;
+    const int id = valid ? (int)(base + lane) : (int)(total - 1);
+    const int env = id / d.R;
+    const int e = id - env * d.R;
+    const bool train = e < d.r;
+    const int dir = train ? e / d.I : 0;
+    const int dst = e - dir * d.I;
+    const int ld = d.leading[id];
+    int lc = d.lastcar[id];
+    const int n_old = ring_count(ld, lc, C);
+    int n_tot = n_old, ovf_sp = 0;
+    float xL = INFINITY, xs0 = 0.0f;
+    if (train) {
+      int ph_new, el_new;
+      light_update(d, env, dst, tick, tidx, ph_new, el_new);
+      const int phase_e = (dir < 2) ? 1 : 0;
+      if (phase_e == ph_new || el_new < d.yellow) {
+        xL = d.length;
+      } else {
+        const int idn = env * d.R + d.nexts[e];
+        if (d.lastcar[idn] != d.leading[idn]) xL = d.tailx[idn] + d.length;
+      }
+    }
+    const int ej = d.entry_idx[e];
+    if (ej >= 0 && valid) {
+      int c;
+      if (d.spawn_mode == TFX_SPAWN_COUNTS)
+        c = d.spawn[(size_t)tidx * d.spawn_stride + (size_t)env * d.n_entry + ej];
+      else if (d.spawn_mode == TFX_SPAWN_PERIODIC)
+        c = (tick_sp == e % d.spawn_period) ? 1 : 0;
+      else
+        c = 0;
+      if (c > 0) {
+        float tail_x = d.tailx[id];
+        for (int q = 0; q < c; ++q) {
+          const int pos = wrap1(lc + 1, C);
+          const float start = (lc != ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+          if (pos != ld) {
+            const float xv = (start < 0.0f) ? start : 0.0f;
+            if (n_tot == n_old) xs0 = xv;
+            ++n_tot;
+            lc = pos;
+            tail_x = xv;
+          } else {
+            ++ovf_sp;
+          }
+        }
+        if (n_tot != n_old) d.lastcar[id] = lc;
+      }
+    }
+    const int pk = pack_desc(ld, lc, n_old, n_tot);
+    const int xL_bits = __float_as_int(xL), xs0_bits = __float_as_int(xs0);
+
+    // ================= phase C: sub-tiles of S roads through LDS =================================
+    const long left = total - base;
+    const int nroads = left < TR ? (int)left : TR;
+    const int idb = (int)base;
+    float *tx = d.state + (size_t)base * stride;  // wave-uniform tile base, 16-byte aligned
+    int r_k = 0, r_w = 0, r_d = 0, r_t = 0;
+
+    for (int j0 = 0; j0 < nroads; j0 += S) {
+      const int ns = (nroads - j0 < S) ? nroads - j0 : S;
+      // ---- LDS-DMA: ns*stride floats = n16 chunks of 16 B, 64 chunks per wave instruction
+      {
+        const float *gsrc = tx + (size_t)j0 * stride;
+        const int n16 = (ns * stride) >> 2;
+        for (int q0 = 0; q0 < n16; q0 += 64) {
+          const int q = q0 + lane;
+          if (q < n16)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(gsrc + (size_t)q * 4), (lptr_t *)(buf + (size_t)q0 * 4),
+                                             16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int jj = 0; jj < S; ++jj) {
+        if (jj < ns) {
+          const int j = j0 + jj;
+          const int pkj = __builtin_amdgcn_readlane(pk, j);
+          const float xLj = __int_as_float(__builtin_amdgcn_readlane(xL_bits, j));
+          const int ldj = pkj & 511, lcj = (pkj >> 9) & 511, n_oldj = (pkj >> 18) & 127;
+          const int n_totj = (int)((unsigned)pkj >> 25);
+          float *rb = buf + jj * stride;          // this road's record in LDS
+          int slot = ldj + 1 + lane;
+          slot = (slot >= C) ? slot - (C - 1) : slot;
+          const bool is_live = lane < n_totj;
+          float x, v, xl, vl;
+          if (LEADER_LDS) {
+            // patch the fake leader into its ring slot, then every car reads ring slot - 1
+            if (lane == 0) {
+              rb[ldj] = xLj;
+              rb[C + ldj] = 0.0f;
+            }
+            if (n_totj != n_oldj) {  // cars spawned this tick are not in memory yet
+              if (lane >= n_oldj && is_live) {
+                float xv = __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j));
+                for (int q = n_oldj; q < lane; ++q) xv = (xv - d.car_l) - d.car_s0;
+                rb[slot] = xv;
+                rb[C + slot] = d.car_v;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int sl = is_live ? slot : 1;
+            const int prev = (sl == 1) ? C - 1 : sl - 1;
+            const int pv = (lane == 0) ? ldj : prev;
+            x = rb[sl];
+            v = rb[C + sl];
+            xl = rb[pv];
+            vl = rb[C + pv];
+          } else {
+            const int sl = (lane < n_oldj) ? slot : 1;
+            x = rb[sl];
+            v = rb[C + sl];
+            if (n_totj != n_oldj) {
+              if (lane >= n_oldj && is_live) {
+                float xv = __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j));
+                for (int q = n_oldj; q < lane; ++q) xv = (xv - d.car_l) - d.car_s0;
+                x = xv;
+                v = d.car_v;
+              }
+            }
+            xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xLj), __float_as_int(x), 0x138, 0xf, 0xf, false));
+            vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+          }
+          const float ll = (lane == 0) ? 0.0f : d.car_l;
+
+          const float t_gap = v * d.car_T;
+          const float appr = v * (v - vl);
+          const float s_star = d.car_s0 + np_max0(t_gap + appr / d.two_sab);
+          const float sgap = (xl - x) - ll;
+          const float q = v / d.car_v0;
+          const float qd = pow4_cr(q);
+          const float u = s_star / (sgap + d.eps);
+          const float dv = d.car_a * ((1.0f - qd) - u * u);
+          const float dvr = dv * d.rate;
+          const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+          const float xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+          const float vn = np_max0(v + dvr);
+
+          const int off = j * stride + slot;
+          if (is_live) {
+            tx[off] = xn;
+            tx[off + C] = vn;
+          }
+          if (lane == 0) tx[j * stride + ldj] = xLj;  // the leader's x stays in its slot
+          if (n_totj != n_oldj && d.P == 3) {
+            if (lane >= n_oldj && is_live) tx[off + 2 * C] = (float)tick;
+          }
+          bool c_wait;
+          if (ldj > lcj)
+            c_wait = ((slot <= lcj) ? xn : vn) < d.thresh;
+          else
+            c_wait = vn < d.thresh;
+          const unsigned long long m_pop = __ballot(is_live && (xn > d.length));
+          const int n_wait = __popcll(__ballot(is_live && c_wait));
+          const int n_det = __popcll(__ballot(is_live && (xn > d.near_end)));
+          int kpop = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+          int tail_bits = 0;
+          if (n_totj > 0) tail_bits = __builtin_amdgcn_readlane(__float_as_int(xn), n_totj - 1);
+          if (kpop > 0) {
+            const bool far = is_live && (xn > d.length) && ((xn - d.length) > d.length);
+            const bool slow = (kpop > KP) || (__ballot(far) != 0ull);
+            if (lane < kpop && lane < KP) {
+              float w = 0.0f;
+              if (d.P == 3) w = (lane >= n_oldj) ? (float)tick : rb[2 * C + slot];
+              float *pc = d.popcar + ((size_t)(idb + j) * KP + lane) * 3;
+              pc[0] = xn;
+              pc[1] = vn;
+              pc[2] = w;
+            }
+            kpop |= slow ? (1 << 30) : 0;
+          }
+          const bool mine = lane == j;
+          r_k = mine ? kpop : r_k;
+          r_w = mine ? n_wait : r_w;
+          r_d = mine ? n_det : r_d;
+          r_t = mine ? tail_bits : r_t;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ================= phase W: lane j writes road j's results ===================================
+    if (valid) {
+      const int kpop = r_k & 0xffff;
+      if (train) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += r_w;
+          ob[d.r + e] = r_d;
+        }
+        ob[e] = kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + dst] = 1;
+      }
+      d.rec[id] = make_int4(kpop, ovf_sp, r_t, n_tot);
+      if ((r_k >> 30) & 1) d.env_flag[env] = tick + 1;
+      my_updates += (unsigned long long)n_tot;
+    }
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Ring pop + handoff for destination road e, pull form.  Returns the overflow count of pushes
 // into e.  Exact restatement of what the reference's sequential loop (advance_finished_cars
 // :117-135) does to road e, given that (a) e's own pops are its first k_e cars and (b) the cars
@@ -886,7 +1395,10 @@ struct tfx_handle_s {
   std::vector<hipEvent_t> ev;
   int ev_ticks = 0, ev_used = 0;
   bool prof = false;
-  int move_variant = 0;  // 0: k_move_tile<2> (default); 4: k_move_tile<4>; 1: k_move<1> (TFX_MOVE_VARIANT, A/B runs)
+  // TFX_MOVE_VARIANT (A/B runs): 0 k_move_w64<2,DPP> (default) | 2 w64<2,LDS> | 5 w64<4,DPP> |
+  // 6 w64<1,DPP> | 3 k_move_tile<2> | 4 k_move_tile<4> | 1 k_move<1>
+  int move_variant = 0;
+  size_t dma_lds(int S) const { return (size_t)4 * S * d.P * d.C * sizeof(float); }
 };
 
 namespace {
@@ -937,9 +1449,9 @@ int check_handle(tfx_handle h, bool need_bound) {
 // Grid of the move kernel: every block resident at once (occupancy query), a multiple of 8 so the
 // XCD-contiguous chunking applies, never more blocks than there is work.
 template <typename K>
-int move_grid(tfx_handle h, K kernel, long work_items_per_block) {
+int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds = 0) {
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess || per_cu < 1)
     per_cu = 4;
   if (per_cu > 8) per_cu = 8;
   const long total = (long)h->d.E * h->d.R;
@@ -955,22 +1467,40 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (h->grid_move == 0) {
     switch (h->wpr) {
       case 1:
-        h->grid_move = h->move_variant == 0   ? move_grid(h, k_move_tile<2>, 256)
-                       : h->move_variant == 4 ? move_grid(h, k_move_tile<4>, 256)
-                                              : move_grid(h, k_move<1>, 4);
+        switch (h->move_variant) {
+          case 7: h->grid_move = move_grid(h, k_move_dma<8, false>, 256, h->dma_lds(8)); break;
+          case 8: h->grid_move = move_grid(h, k_move_dma<8, true>, 256, h->dma_lds(8)); break;
+          case 9: h->grid_move = move_grid(h, k_move_dma<16, false>, 256, h->dma_lds(16)); break;
+          case 10: h->grid_move = move_grid(h, k_move_dma<4, false>, 256, h->dma_lds(4)); break;
+          case 0: h->grid_move = move_grid(h, k_move_w64<2, false>, 256); break;
+          case 2: h->grid_move = move_grid(h, k_move_w64<2, true>, 256); break;
+          case 5: h->grid_move = move_grid(h, k_move_w64<4, false>, 256); break;
+          case 6: h->grid_move = move_grid(h, k_move_w64<1, false>, 256); break;
+          case 3: h->grid_move = move_grid(h, k_move_tile<2>, 256); break;
+          case 4: h->grid_move = move_grid(h, k_move_tile<4>, 256); break;
+          default: h->grid_move = move_grid(h, k_move<1>, 4); break;
+        }
         break;
       case 2: h->grid_move = move_grid(h, k_move<2>, 2); break;
       default: h->grid_move = move_grid(h, k_move<4>, 1); break;
     }
   }
+  const dim3 gr(h->grid_move), bl(256);
   switch (h->wpr) {
     case 1:
-      if (h->move_variant == 0)
-        hipLaunchKernelGGL(k_move_tile<2>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
-      else if (h->move_variant == 4)
-        hipLaunchKernelGGL(k_move_tile<4>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
-      else
-        hipLaunchKernelGGL(k_move<1>, dim3(h->grid_move), dim3(256), 0, st, d, tidx);
+      switch (h->move_variant) {
+        case 7: hipLaunchKernelGGL((k_move_dma<8, false>), gr, bl, h->dma_lds(8), st, d, tidx); break;
+        case 8: hipLaunchKernelGGL((k_move_dma<8, true>), gr, bl, h->dma_lds(8), st, d, tidx); break;
+        case 9: hipLaunchKernelGGL((k_move_dma<16, false>), gr, bl, h->dma_lds(16), st, d, tidx); break;
+        case 10: hipLaunchKernelGGL((k_move_dma<4, false>), gr, bl, h->dma_lds(4), st, d, tidx); break;
+        case 0: hipLaunchKernelGGL((k_move_w64<2, false>), gr, bl, 0, st, d, tidx); break;
+        case 2: hipLaunchKernelGGL((k_move_w64<2, true>), gr, bl, 0, st, d, tidx); break;
+        case 5: hipLaunchKernelGGL((k_move_w64<4, false>), gr, bl, 0, st, d, tidx); break;
+        case 6: hipLaunchKernelGGL((k_move_w64<1, false>), gr, bl, 0, st, d, tidx); break;
+        case 3: hipLaunchKernelGGL(k_move_tile<2>, gr, bl, 0, st, d, tidx); break;
+        case 4: hipLaunchKernelGGL(k_move_tile<4>, gr, bl, 0, st, d, tidx); break;
+        default: hipLaunchKernelGGL(k_move<1>, gr, bl, 0, st, d, tidx); break;
+      }
       break;
     case 2: hipLaunchKernelGGL(k_move<2>, dim3(h->grid_move), dim3(256), 0, st, d, tidx); break;
     default: hipLaunchKernelGGL(k_move<4>, dim3(h->grid_move), dim3(256), 0, st, d, tidx); break;
@@ -1020,6 +1550,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   h->cfg = *cfg;
   build_tables(h);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
+  if (h->move_variant >= 7 && (cfg->planes * cfg->capacity) % 4 != 0) h->move_variant = 0;  // records not 16-B multiples
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

@@ -20,8 +20,12 @@
  *     threads (the reference's kernels are nogil and A3C steps envs from threads, a3c.py:69-72).
  *
  * Device data layout (all little-endian, C-contiguous)
- *   state      float32 [E][R][P][C]   P = 2 planes (x, v) or 3 (x, v, w); slot s of road e is the
- *                                     reference's state[e, {xi,vi,wi}, s] (traffic_env.py:34,364).
+ *   xv         float32 [E][R][C][2]   (x, v) of the car in ring slot s of road e = the reference's
+ *                                     state[e, xi, s], state[e, vi, s] (traffic_env.py:34,364),
+ *                                     interleaved so a road's live cars are ONE contiguous span
+ *                                     and a car is one 8-byte access.  16-byte aligned.
+ *   w          float32 [E][R][C]      state[e, wi, s], the spawn tick (validate-mode trip times);
+ *                                     present when tfx_config.planes == 3, else NULL.
  *                                     The other 7 per-car parameters are per-archetype constants
  *                                     (traffic_env.py:35-43) and live in tfx_config.
  *   leading    int32   [E][R]         slot of the fake leader  (README.md:14-23 of the reference)
@@ -41,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 1
+#define TFX_ABI_VERSION 2
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -73,7 +77,7 @@ typedef struct tfx_config {
   int32_t m, n;          /* GridRoad(m, n, l): I = m*n, r = 4I, R = r + 2m + 2n (roadgraph.py:26-33) */
   int32_t capacity;      /* CAPACITY, slots per road incl. slot 0 and the fake leader (traffic_env.py:24) */
   int32_t n_envs;        /* E */
-  int32_t planes;        /* 2 or 3 */
+  int32_t planes;        /* 2: (x, v) only; 3: the w array is carried too */
   float length;          /* graph.len */
   float rate;            /* FLAGS.rate, seconds per tick (traffic_env.py:12) */
   /* the archetype, traffic_env.py:35-43 */
@@ -92,7 +96,8 @@ typedef struct tfx_config {
 } tfx_config;
 
 typedef struct tfx_buffers {
-  float *state;
+  float *xv;
+  float *w;
   int32_t *leading;
   int32_t *lastcar;
   int32_t *obs;

@@ -65,16 +65,29 @@ def assert_same_state(eng, orc, where=""):
     assert np.array_equal(eng.rewards.cpu().numpy(), orc.rewards), "rewards " + where
     assert np.array_equal(eng.waiting.cpu().numpy(), orc.waiting), "waiting " + where
     assert np.array_equal(eng.passed_dst.cpu().numpy(), orc.passed_dst), "passed_dst " + where
-    st = eng.state.cpu().numpy()
+    st = eng.planes_numpy()
     rows = np.arange(eng.R)
     for k in range(eng.E):
         live = live_mask(ld[k], lc[k], eng.C)
         for plane, name, oplane in ((0, "x", orc.x[k]), (1, "v", orc.v[k]), (2, "w", orc.w[k])):
-            a, b = st[k, :, plane, :][live], oplane[live]
+            a, b = st[plane][k][live], oplane[live]
             assert same_bits(a, b), "%s env %d %s" % (name, k, where)
         # the fake leader's x sits in its slot, as in the reference
-        a, b = st[k, rows, 0, ld[k]], orc.x[k][rows, ld[k]]
+        a, b = st[0][k][rows, ld[k]], orc.x[k][rows, ld[k]]
         assert same_bits(a, b), "leader x env %d %s" % (k, where)
+
+
+def assert_engines_equal(a, b):
+    """Two HIP engines hold the same defined state: ring indices, counters and the (x, v, w) of
+    every live car, bit for bit.  Dead ring slots hold junk by design and are not compared."""
+    for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst", "done"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    ld, lc = a.leading.cpu().numpy(), a.lastcar.cpu().numpy()
+    pa, pb = a.planes_numpy(), b.planes_numpy()
+    for k in range(a.E):
+        live = live_mask(ld[k], lc[k], a.C)
+        for u, v, name in zip(pa, pb, "xvw"):
+            assert same_bits(u[k][live], v[k][live]), "%s env %d" % (name, k)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -150,12 +163,12 @@ def test_teacher_forced_vs_golden(name, golden_cache):
         assert np.array_equal(eng.waiting[0].cpu().numpy(), g["waiting"][k]), (name, k)
         assert np.array_equal(eng.passed_dst[0].cpu().numpy(), g["passed_dst"][k]), (name, k)
         assert int(eng.done[0]) == int(g["done"][k])
-        st = eng.state[0].cpu().numpy()
+        sx, sv, sw = [a[0] for a in eng.planes_numpy()]
         live = live_mask(ld, lc, sc["C"])
         if live.any():
-            assert ulp_diff(st[:, 0, :][live], g["state_x"][k][live]).max() <= 1
-            assert ulp_diff(st[:, 1, :][live], g["state_v"][k][live]).max() <= 1
-            assert np.array_equal(st[:, 2, :][live], g["state_w"][k][live])
+            assert ulp_diff(sx[live], g["state_x"][k][live]).max() <= 1
+            assert ulp_diff(sv[live], g["state_v"][k][live]).max() <= 1
+            assert np.array_equal(sw[live], g["state_w"][k][live])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -260,11 +273,11 @@ def test_kernel_halves_vs_oracle():
     eng.move_cars()
     orc.elapsed[:] += 1
     orc.move_cars()
-    st = eng.state.cpu().numpy()
+    sx, sv, _ = eng.planes_numpy()
     for k in range(E):
         live = live_mask(leading[k], lastcar[k], C)
-        assert same_bits(st[k, :, 0, :][live], orc.x[k][live])
-        assert same_bits(st[k, :, 1, :][live], orc.v[k][live])
+        assert same_bits(sx[k][live], orc.x[k][live])
+        assert same_bits(sv[k][live], orc.v[k][live])
     assert np.array_equal(eng.waiting.cpu().numpy(), orc.waiting)
     assert np.array_equal(eng.detected.cpu().numpy(), orc.detected)
     eng.advance_finished_cars()
@@ -327,8 +340,7 @@ def test_multi_tick_call_equals_single_ticks():
         b.set_actions(acts[t])
         b.set_spawns(counts=sp[t])
         b.step(1)
-    for name in ("state", "leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
-        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert_engines_equal(a, b)
     assert a.tick == b.tick == T
 
 
@@ -353,8 +365,7 @@ def test_on_device_controllers_match_host_rule():
         b.set_spawns(counts=c)
         b.set_actions(act)
         b.step(1)
-    for name in ("state", "leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
-        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert_engines_equal(a, b)
     assert int(a.cars_on_roads_flat().sum()) > 50
 
 

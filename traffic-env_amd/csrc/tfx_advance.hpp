@@ -1,0 +1,204 @@
+// tfx_advance.hpp - k_advance: ring pop + car handoff (advance_finished_cars, traffic_env.py:117-135,
+// and its validate-mode twin advance_hack :139-157), plus the per-intersection stores of the tick
+// (phase, elapsed, rewards, done).
+//
+// The reference walks roads sequentially.  Here every road PULLS the cars its unique predecessor
+// popped (k_move left them in the per-road record), one lane per intersection (its four incoming
+// roads) or exit road.  The pull form is exact whenever every road pops at most TFX_KP cars and no
+// handed-off car could be popped again in the same tick; k_move detects the contrary per env and
+// that env then goes through advance_env_serial, a literal single-thread restatement - so results
+// equal the sequential algorithm in every case.
+#pragma once
+#include "tfx_common.hpp"
+
+namespace tfx {
+
+// Ring pop + handoff for destination road e.  Returns the overflow count of pushes into e.
+// What the reference's loop does to road e, given that (a) e's own pops are its first k_e cars and
+// (b) the cars pushed into e are the k_p cars its predecessor p popped (read straight from p's ring:
+// k_move left their post-move state in slots head_p, head_p+1, ...):
+//   - the loop visits roads in ascending order, so p's pushes see leading[e] BEFORE e's own pops
+//     when p < e and AFTER them when p > e (both the ring-full test and the empty-road test of
+//     add_car :100-105 read leading[e]);
+//   - successive pushes queue behind each other: start = x_tail - l - s0 of the previous push.
+// Who writes what (no two lanes touch the same word): road e's lane writes e's leading, lastcar,
+// tail cache and the slots it pushes into; it also finishes p's pop by copying p's fake-leader x
+// into p's new leader slot (:133) - the one slot of p that only e's lane reads.
+__device__ __forceinline__ int advance_road(const Dev &d, int env, int e, int tick, int tidx) {
+  const int C = d.C;
+  const int id = env * d.R + e;
+  const int ld = d.leading[id];
+  const int lc0 = d.lastcar[id];
+  int lc = lc0;
+  const int4 rc = d.rec[id];
+  const int k_e = rec_kpop(rc.x);
+  const float tail0 = d.tailx[id];  // e's tail before this tick's move: what p's fake leader saw
+  float tail_x = __int_as_float(rc.z);
+  const int ld_post = ring_adv(ld, k_e, C);
+  float2 *rx = d.xv + (size_t)id * C;
+
+  int ovf = 0;
+  const int p = d.pred[e];
+  if (p >= 0) {
+    const int idp = env * d.R + p;
+    const int rpx = d.rec[idp].x;
+    const int k_p = rec_kpop(rpx);
+    if (k_p > 0) {
+      const int ld_seen = (p < e) ? ld : ld_post;
+      float2 *px = d.xv + (size_t)idp * C;
+      int ps = rec_head(rpx);
+      for (int j = 0; j < k_p; ++j) {
+        const float2 car = px[ps];
+        const float xc = car.x - d.length;  // state[e,xi,newlead] -= length (:130)
+        const int pos = wrap1(lc + 1, C);
+        const float start = (lc != ld_seen) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+        if (pos != ld_seen) {
+          const float xv = (start < xc) ? start : xc;
+          rx[pos] = make_float2(xv, car.y);
+          if (d.w) d.w[(size_t)id * C + pos] = d.w[(size_t)idp * C + ps];
+          lc = pos;
+          tail_x = xv;
+        } else {
+          ++ovf;
+        }
+        if (j + 1 < k_p) ps = wrap1(ps + 1, C);
+      }
+      d.lastcar[id] = lc;
+      // p's new leader slot (its last popped car) gets p's fake-leader x (:133), recomputed the
+      // way update_lights (:81-94) set it this tick: from p's light and e's tail before the move
+      int ph_new, el_new;
+      const int dirp = p / d.I;
+      light_update(d, env, p - dirp * d.I, tick, tidx, ph_new, el_new);
+      float xLp = INFINITY;
+      if (((dirp < 2) ? 1 : 0) == ph_new || el_new < d.yellow) xLp = d.length;
+      else if (lc0 != ld) xLp = tail0 + d.length;
+      px[ps].x = xLp;
+    }
+  }
+  if (k_e > 0) {
+    d.leading[id] = ld_post;
+    if (e >= d.r) rx[ld_post].x = INFINITY;  // exit roads: nobody pulls, the leader stays at +inf
+  }
+  d.tailx[id] = tail_x;
+  return ovf;
+}
+
+// Literal single-thread advance for one env (taken when a road popped more than TFX_KP cars or a
+// handed-off car could itself be popped again this tick).  Follows :117-157 line by line.
+__device__ void advance_env_serial(const Dev &d, int env, int tick) {
+  const int C = d.C;
+  int *ob = d.obs + (size_t)env * d.obs_len;
+  float *rew = d.rewards + (size_t)env * d.I;
+  int overflowed = 0;
+  for (int i = 0; i < d.I; ++i) rew[i] = 0.0f;
+  for (int e = 0; e < d.R; ++e) {
+    const int sp = d.rec[env * d.R + e].y;  // spawn overflows happened before move_cars
+    if (sp > 0) {
+      overflowed = 1;
+      if (e < d.r)
+        for (int j = 0; j < sp; ++j) rew[e % d.I] -= d.ovf_pen;
+    }
+  }
+  for (int e = 0; e < d.r; ++e) ob[e] = 0;
+  for (int e = 0; e < d.R; ++e) {
+    const int id = env * d.R + e;
+    float2 *rx = d.xv + (size_t)id * C;
+    float *rw = d.w ? d.w + (size_t)id * C : nullptr;
+    int ld = d.leading[id];
+    while (ld != d.lastcar[id] && rx[wrap1(ld + 1, C)].x > d.length) {
+      const int newlead = wrap1(ld + 1, C);
+      const int nr = d.nexts[e];
+      if (nr >= 0) {
+        ob[e] += 1;
+        d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+        rx[newlead].x -= d.length;
+        const int idn = env * d.R + nr;
+        float2 *nx = d.xv + (size_t)idn * C;
+        const int lcn = d.lastcar[idn], ldn = d.leading[idn];
+        const int pos = wrap1(lcn + 1, C);
+        const float start = (lcn != ldn) ? (nx[lcn].x - d.car_l) - d.car_s0 : INFINITY;
+        if (pos != ldn) {
+          const float xc = rx[newlead].x;
+          nx[pos] = make_float2((start < xc) ? start : xc, rx[newlead].y);
+          if (rw) d.w[(size_t)idn * C + pos] = rw[newlead];
+          d.lastcar[idn] = pos;
+        } else {
+          if (nr < d.r) rew[nr % d.I] -= d.ovf_pen;
+          overflowed = 1;
+        }
+      } else if (d.validate && d.n_trips) {
+        const int t = d.n_trips[env];
+        if (d.trip_times && t < d.trip_cap)
+          d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - (rw ? rw[newlead] : 0.0f)) / 2.0f;
+        d.n_trips[env] = t + 1;
+      }
+      rx[newlead].x = rx[ld].x;
+      ld = newlead;
+      d.leading[id] = ld;
+    }
+  }
+  for (int e = 0; e < d.R; ++e) {
+    const int id = env * d.R + e;
+    d.tailx[id] = d.xv[(size_t)id * C + d.lastcar[id]].x;
+  }
+  if (overflowed) d.done_tick[env] = tick + 1;
+}
+
+__global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
+  const int tick = *d.tickB;
+  const int n_exit = d.R - d.r;
+  const int per_env = d.I + n_exit;
+  const long total = (long)d.E * per_env;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+       gid += (long)gridDim.x * blockDim.x) {
+    const int env = (int)(gid / per_env);
+    const int s = (int)(gid - (long)env * per_env);
+    const bool serial = d.env_flag[env] == tick + 1;
+    if (serial && s == 0) advance_env_serial(d, env, tick);
+    if (s < d.I) {
+      // intersection s: its four incoming roads s, I+s, 2I+s, 3I+s (roadgraph.py:38-39)
+      int ph_new, el_new;
+      light_update(d, env, s, tick, tidx, ph_new, el_new);
+      if (!serial) {
+        int ovf = 0;
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir) {
+          const int e = dir * d.I + s;
+          ovf += advance_road(d, env, e, tick, tidx) + d.rec[env * d.R + e].y;
+        }
+        // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
+        float rw = 0.0f;
+        for (int j = 0; j < ovf; ++j) rw -= d.ovf_pen;
+        d.rewards[(size_t)env * d.I + s] = rw;
+        if (ovf > 0) d.done_tick[env] = tick + 1;
+      }
+      int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+      ob[s] = ph_new;
+      ob[d.I + s] = el_new;
+    } else if (!serial) {
+      const int e = d.r + (s - d.I);
+      const int ovf = advance_road(d, env, e, tick, tidx);
+      if (ovf > 0) d.done_tick[env] = tick + 1;
+      if (d.validate && d.n_trips && s == d.I) {
+        // advance_hack :153-154: trip times of cars leaving the map, in road order
+        int t = d.n_trips[env];
+        for (int x = d.r; x < d.R; ++x) {
+          const int idx = env * d.R + x;
+          const int rxx = d.rec[idx].x;
+          int ps = rec_head(rxx);
+          for (int j = 0; j < rec_kpop(rxx); ++j) {
+            if (d.trip_times && t < d.trip_cap)
+              d.trip_times[(size_t)env * d.trip_cap + t] =
+                  ((float)tick - (d.w ? d.w[(size_t)idx * d.C + ps] : 0.0f)) / 2.0f;
+            ++t;
+            ps = wrap1(ps + 1, d.C);
+          }
+        }
+        d.n_trips[env] = t;
+      }
+    }
+    if (gid == 0) *d.tickA = tick + 1;
+  }
+}
+
+}  // namespace tfx

@@ -1,0 +1,191 @@
+// tfx_common.hpp - device parameter block and the arithmetic every kernel shares.
+//
+// Float contract (bit-for-bit shared with oracle/idm_oracle.c): binary32, the reference's
+// expression order (gym_traffic/envs/traffic_env.py:50-62), one rounding per operation
+// (-ffp-contract=off), correctly rounded divide, q^4 from two binary64 multiplies,
+// np.maximum(0, t) as (0 >= t ? 0 : t), (dx > 0) * dx as (dx > 0 ? dx : 0 * dx).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "tfx.h"
+
+namespace tfx {
+
+constexpr int KP = TFX_KP;
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+  int I, r, R, C, E, n_entry, obs_len;
+  int yellow, learn_switch, validate, env_off;
+  int dbg;  // TFX_DEBUG ablation bits (timing experiments only; results are wrong when set)
+  float length, rate, car_v, car_l, car_a, car_v0, car_b, car_T, car_s0;
+  float two_sab, eps, thresh, near_end, ovf_pen;
+  // caller-owned state
+  float2 *xv;  // [E][R][C] (x, v) per ring slot
+  float *w;    // [E][R][C] spawn tick per ring slot, or nullptr
+  int *leading, *lastcar, *obs;
+  float *rewards;
+  int *waiting;
+  uint8_t *passed_dst;
+  int *done_tick;
+  float *trip_times;
+  int *n_trips;
+  int trip_cap;
+  // handle-owned tables + scratch
+  const int *nexts, *pred, *entry_idx;
+  int4 *rec;      // per road: {pops k | head slot << 8, spawn overflows, bits of post-move tail x, live cars}
+  float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
+  int *env_flag;  // == tick+1 when the env must take the serial advance this tick
+  unsigned long long *veh;
+  int *tickA, *tickB;
+  // per-tick inputs
+  const int *action;
+  int action_mode, action_period;
+  long action_stride;
+  const int *spawn;
+  int spawn_mode, spawn_period;
+  long spawn_stride;
+};
+
+__device__ __forceinline__ float np_max0(float t) { return (0.0f >= t) ? 0.0f : t; }
+__device__ __forceinline__ float pow4_cr(float q) {
+  const double q2 = (double)q * (double)q;
+  return (float)(q2 * q2);
+}
+// traffic_env.py:46-47
+__device__ __forceinline__ int wrap1(int a, int C) { return a >= C ? 1 : a; }
+// slot reached from `slot` (1..C-1) after k (0..C-1) ring steps
+__device__ __forceinline__ int ring_adv(int slot, int k, int C) {
+  const int s = slot + k;
+  return s >= C ? s - (C - 1) : s;
+}
+// traffic_env.py:214-218
+__device__ __forceinline__ int ring_count(int ld, int lc, int C) { return lc - ld + (ld > lc ? C - 1 : 0); }
+
+// sim (traffic_env.py:50-62) for one car: (x, v) against its leader (xl, vl, length ll).
+__device__ __forceinline__ void idm_step(const Dev &d, float x, float v, float xl, float vl, float ll,
+                                         float &xn, float &vn) {
+  const float t_gap = v * d.car_T;
+  const float appr = v * (v - vl);
+  const float s_star = d.car_s0 + np_max0(t_gap + appr / d.two_sab);
+  const float s = (xl - x) - ll;
+  const float q = v / d.car_v0;
+  const float qd = pow4_cr(q);
+  const float u = s_star / (s + d.eps);
+  const float dv = d.car_a * ((1.0f - qd) - u * u);
+  const float dvr = dv * d.rate;
+  const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+  xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+  vn = np_max0(v + dvr);
+}
+
+// TrafficEnv._step lines :225-232 for one intersection: new phase and elapsed from the old ones.
+__device__ __forceinline__ void light_update(const Dev &d, int env, int i, int tick, int tidx,
+                                             int &ph_new, int &el_new) {
+  const int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+  const int ph = ob[i], el = ob[d.I + i];
+  int a;
+  if (d.action_mode == TFX_ACTION_CYCLE)
+    a = ((tick + (env + d.env_off) % d.action_period) / d.action_period) & 1;
+  else if (d.action_mode == TFX_ACTION_BROADCAST)
+    a = d.action[(size_t)tidx * d.action_stride + i];
+  else
+    a = d.action[(size_t)tidx * d.action_stride + (size_t)env * d.I + i];
+  int change;
+  if (d.learn_switch) {
+    change = a != 0;
+    ph_new = ((ph != 0) != (a != 0)) ? 1 : 0;
+  } else {
+    change = (ph != 0) != (a != 0);
+    ph_new = a;
+  }
+  el_new = change ? 0 : el + 1;
+}
+
+// cars add_new_cars (traffic_env.py:274-283) puts on entry road e (entry index ej) this tick
+__device__ __forceinline__ int spawn_count(const Dev &d, int env, int e, int ej, int tick_mod_period, int tidx) {
+  if (d.spawn_mode == TFX_SPAWN_COUNTS)
+    return d.spawn[(size_t)tidx * d.spawn_stride + (size_t)env * d.n_entry + ej];
+  if (d.spawn_mode == TFX_SPAWN_PERIODIC) return (tick_mod_period == e % d.spawn_period) ? 1 : 0;
+  return 0;
+}
+
+// Phase-M work shared by the move kernels: everything about road (env, e) that does not need the
+// cars - ring indices, the fake leader's x from the light state (update_lights :81-94) and the
+// spawn pushes (add_car :97-114).  `valid` lanes evaluate the spawns; the lane with `store` set
+// also writes the new lastcar (several lanes may prepare the same road redundantly).
+struct RoadPrep {
+  int ld, lc, n_old, n_tot, ovf_sp;
+  float xL, xs0;  // fake-leader x; x of the first car spawned this tick
+};
+
+__device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int e, int tick,
+                                              int tick_mod_period, int tidx, bool valid, bool store) {
+  const int C = d.C;
+  RoadPrep p;
+  p.ld = d.leading[id];
+  p.lc = d.lastcar[id];
+  p.n_old = ring_count(p.ld, p.lc, C);
+  p.n_tot = p.n_old;
+  p.ovf_sp = 0;
+  p.xL = INFINITY;
+  p.xs0 = 0.0f;
+  if (e < d.r) {
+    const int dir = e / d.I;
+    int ph_new, el_new;
+    light_update(d, env, e - dir * d.I, tick, tidx, ph_new, el_new);
+    const int phase_e = (dir < 2) ? 1 : 0;  // roadgraph.py:36
+    if (phase_e == ph_new || el_new < d.yellow) {
+      p.xL = d.length;
+    } else {
+      const int idn = env * d.R + d.nexts[e];
+      if (d.lastcar[idn] != d.leading[idn]) p.xL = d.tailx[idn] + d.length;
+    }
+  }
+  const int ej = d.entry_idx[e];
+  if (ej >= 0 && valid) {
+    const int c = spawn_count(d, env, e, ej, tick_mod_period, tidx);
+    if (c > 0) {
+      float tail_x = d.tailx[id];
+      for (int q = 0; q < c; ++q) {
+        const int pos = wrap1(p.lc + 1, C);
+        const float start = (p.lc != p.ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+        if (pos != p.ld) {
+          const float xv = (start < 0.0f) ? start : 0.0f;  // min(car.x = 0, start)
+          if (p.n_tot == p.n_old) p.xs0 = xv;
+          ++p.n_tot;
+          p.lc = pos;
+          tail_x = xv;
+        } else {
+          ++p.ovf_sp;
+        }
+      }
+      if (store && p.n_tot != p.n_old) d.lastcar[id] = p.lc;
+    }
+  }
+  return p;
+}
+
+// rec.x of a road: number of cars popped this tick (they sit in ring slots head, head+1, ...)
+__device__ __forceinline__ int rec_pack(int kpop, int ld, int C) { return kpop | (wrap1(ld + 1, C) << 8); }
+__device__ __forceinline__ int rec_kpop(int rx) { return rx & 255; }
+__device__ __forceinline__ int rec_head(int rx) { return rx >> 8; }
+
+// The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car
+// would itself be popped again downstream this tick, or (c) a full ring pops two or more cars
+// while receiving pushes (a push could then reuse a popped slot its puller still has to read).
+__device__ __forceinline__ bool needs_serial(int kpop, bool any_far, int n_tot, int C) {
+  return (kpop > KP) || any_far || (kpop >= 2 && n_tot >= C - 2);
+}
+
+// x of the j-th car spawned this tick (j = 0 is xs0): each queues behind the previous one
+__device__ __forceinline__ float spawned_x(const Dev &d, float xs0, int j) {
+  float xv = xs0;
+  for (int q = 0; q < j; ++q) xv = (xv - d.car_l) - d.car_s0;
+  return xv;
+}
+
+}  // namespace tfx

@@ -1,0 +1,235 @@
+// tfx_move_dma.hpp - k_move_dma: the HBM-facing move kernel for rings of at most 64 cars.
+//
+// A wavefront owns a TILE of 64 consecutive roads and works in three wave-local phases (no block
+// barrier; the four waves of a block are independent):
+//   M  lane j prepares road j of the tile (prep_road): ring indices, light state -> fake-leader x,
+//      spawn pushes.  All per-road scalar work happens 64 roads at a time with coalesced loads.
+//      The lane keeps the result in registers; phase C fetches it with v_readlane, so per-road
+//      values are SGPRs there.
+//   C  sub-tiles of S consecutive roads are one contiguous 16-byte-aligned span of S*C (x, v)
+//      pairs, copied to LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per
+//      instruction, no VGPR holds the bytes in flight).  With NBUF = 2 the next sub-tile is in
+//      flight while the current one is computed (counted s_waitcnt vmcnt).  Per road, lane k reads
+//      car k's (x, v) from the image by ring slot (one ds_read_b64), finds its leader either one
+//      ring slot ahead in the image (LEADER_LDS: the +1 LDS access) or by a DPP wave shift that
+//      injects the fake leader into lane 0, runs the IDM and writes the new (x, v) back into the
+//      image.  The four per-road predicates (waiting, detected, crossed the road end, far beyond
+//      it) become four 64-bit ballots that go to lane j with v_writelane - no scalar counting in
+//      the loop.  The finished sub-tile is written back to HBM as it came, 16 B per lane.
+//   W  lane j turns road j's ballots into waiting / detected / passed counts, the pop prefix and
+//      the handoff record, and writes them coalesced.
+// CC > 0 fixes the ring capacity at compile time (immediate offsets, constexpr DMA counts);
+// CC = 0 reads it from the config (single-buffered only).  Needs an even capacity (16-byte road
+// records); otherwise the generic k_move<1> is used.
+#pragma once
+#include "tfx_common.hpp"
+
+namespace tfx {
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// v_writelane_b32: put a wave-uniform value into one lane of a VGPR (no clang builtin on this
+// toolchain; the LLVM intrinsic keeps it visible to the scheduler and the hazard recogniser)
+extern "C" __device__ int tfx_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+__device__ __forceinline__ int pack_desc(int ld, int lc, int n_old, int n_tot) {
+  return ld | (lc << 9) | (n_old << 18) | (n_tot << 25);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ unsigned long long lane_mask_below(int n) {  // lanes 0 .. n-1
+  return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+}
+
+template <int CC, int S, int NBUF, int UNR, bool LEADER_LDS>
+__global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
+  static_assert(NBUF == 1 || CC > 0, "double buffering needs a compile-time capacity");
+  constexpr int TR = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  // wave index made provably uniform: everything derived from it (tile, base pointers, road
+  // counts) then lives in SGPRs and every branch on it is a scalar branch
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
+  const int C = CC ? CC : d.C;
+  const int sub_slots = S * C;  // (x, v) pairs per sub-tile
+  float2 *bufs = reinterpret_cast<float2 *>(smem) + (size_t)wv * NBUF * sub_slots;
+  constexpr int K_DMA = CC ? (S * CC * 8 + 1023) / 1024 : 0;  // DMA instructions per full sub-tile
+  const bool all_slots = (C - 1 >= 64);  // every lane's ring slot is a valid slot of the image
+
+  // tiles are dealt round-robin over all waves of the grid: at any moment the waves in flight
+  // cover one dense window of memory (DRAM rows are used while they are open)
+  const long total = (long)d.E * d.R;
+  const long tiles = (total + TR - 1) / TR;
+  const long nw = (long)gridDim.x * 4;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+  const float ll = (lane == 0) ? 0.0f : d.car_l;  // the fake leader has length 0
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
+    const long base = tile * TR;
+    // ================= phase M: lane j <-> road base + j ========================================
+    const bool valid = base + lane < total;
+    const int id = valid ? (int)(base + lane) : (int)(total - 1);
+    const int env = id / d.R;
+    const int e = id - env * d.R;
+    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, valid, valid);
+    const int pk = pack_desc(p.ld, p.lc, p.n_old, p.n_tot);
+    const int xL_bits = __float_as_int(p.xL), xs0_bits = __float_as_int(p.xs0);
+
+    // ================= phase C: sub-tiles of S roads through LDS =================================
+    const long left = total - base;
+    const int nroads = left < TR ? (int)left : TR;
+    float2 *tx = d.xv + (size_t)base * C;  // wave-uniform tile base, 16-byte aligned
+    // road j's ballots, collected by lane j
+    int mw0 = 0, mw1 = 0, md0 = 0, md1 = 0, mp0 = 0, mp1 = 0, mf0 = 0, mf1 = 0, r_t = 0;
+
+    auto issue = [&](int j0, float2 *dst) {
+      const int ns = (nroads - j0 < S) ? nroads - j0 : S;
+      const float2 *gsrc = tx + (size_t)j0 * C;
+      const int n16 = (ns * C) >> 1;  // 16-byte chunks
+      for (int q0 = 0; q0 < n16; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < n16)
+          __builtin_amdgcn_global_load_lds((gptr_t *)(gsrc + (size_t)q * 2), (lptr_t *)(dst + (size_t)q0 * 2), 16, 0, 0);
+      }
+    };
+
+    if (NBUF == 2) issue(0, bufs);
+    int sub = 0;
+    for (int j0 = 0; j0 < nroads; j0 += S, ++sub) {
+      const int ns = (nroads - j0 < S) ? nroads - j0 : S;
+      float2 *buf = bufs + (NBUF == 2 ? (sub & 1) * sub_slots : 0);
+      if (NBUF == 2) {
+        const int jn = j0 + S;
+        if (jn + S <= nroads) {
+          // a full next sub-tile: leave exactly its K_DMA loads in flight (+ the K_DMA write-back
+          // stores of the previous sub-tile, which are younger than the loads being waited for)
+          issue(jn, bufs + ((sub + 1) & 1) * sub_slots);
+          if (sub > 0) wait_vmcnt<2 * K_DMA>(); else wait_vmcnt<K_DMA>();
+        } else {
+          if (jn < nroads) issue(jn, bufs + ((sub + 1) & 1) * sub_slots);
+          wait_vmcnt<0>();
+        }
+      } else {
+        issue(j0, buf);
+        wait_vmcnt<0>();
+      }
+
+      for (int jj0 = 0; jj0 < ns; jj0 += UNR) {
+#pragma unroll
+        for (int ju = 0; ju < UNR; ++ju) {
+          const int jj = jj0 + ju;
+          if (jj < ns) {
+            const int j = j0 + jj;
+            const int pkj = __builtin_amdgcn_readlane(pk, j);
+            const float xLj = __int_as_float(__builtin_amdgcn_readlane(xL_bits, j));
+            const int ldj = pkj & 511, lcj = (pkj >> 9) & 511, n_oldj = (pkj >> 18) & 127;
+            const int n_totj = (int)((unsigned)pkj >> 25);
+            float2 *rb = buf + jj * C;  // this road's record in LDS
+            // ring slot of car `lane`: positions run 0 .. C-2 from slot 1
+            const unsigned pos = (unsigned)(ldj + lane);               // (ld - 1) + (lane + 1)
+            const unsigned slot = 1u + min(pos, pos - (unsigned)(C - 1));
+            const bool in_img = all_slots || lane < C - 1;
+            const unsigned sl = in_img ? slot : 1u;
+            const float2 cv = rb[sl];
+            float x = cv.x, v = cv.y;
+            if (n_totj != n_oldj) {  // wave-uniform: cars spawned this tick are not in memory yet
+              if (lane >= n_oldj && lane < n_totj) {
+                x = spawned_x(d, __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j)), lane - n_oldj);
+                v = d.car_v;
+              }
+            }
+            float xl, vl;
+            if (LEADER_LDS && n_totj == n_oldj) {
+              // the car one ring slot ahead in the image; lane 0's leader is the fake one
+              const unsigned prev = (sl == 1u) ? (unsigned)(C - 1) : sl - 1u;
+              const float2 lv = rb[prev];
+              xl = (lane == 0) ? xLj : lv.x;
+              vl = (lane == 0) ? 0.0f : lv.y;
+            } else {
+              // wave_shr:1 - lane k receives lane k-1; lane 0 keeps `old` = the fake leader
+              xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xLj), __float_as_int(x), 0x138, 0xf, 0xf, false));
+              vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+            }
+
+            float xn, vn;
+            idm_step(d, x, v, xl, vl, ll, xn, vn);
+
+            // new state back into the image: lanes without a car rewrite dead slots with junk,
+            // which nothing reads (the 64 lanes cover every ring slot except `leading`)
+            if (in_img) rb[sl] = make_float2(xn, vn);
+            if (n_totj != n_oldj && d.w) {
+              if (lane >= n_oldj && lane < n_totj) d.w[(size_t)base * C + j * C + slot] = (float)tick;
+            }
+            // wrapped ring: the reference tests x, not v, on the second segment (:210)
+            const unsigned lc_seg2 = (ldj > lcj) ? (unsigned)lcj : 0u;
+            const float wq = (slot <= lc_seg2) ? xn : vn;
+            const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(wq < d.thresh);
+            const unsigned long long m_det = __builtin_amdgcn_ballot_w64(xn > d.near_end);
+            const unsigned long long m_pop = __builtin_amdgcn_ballot_w64(xn > d.length);
+            const unsigned long long m_far = __builtin_amdgcn_ballot_w64((xn - d.length) > d.length);
+            mw0 = tfx_writelane_i32((int)(unsigned)m_wait, j, mw0);
+            mw1 = tfx_writelane_i32((int)(unsigned)(m_wait >> 32), j, mw1);
+            md0 = tfx_writelane_i32((int)(unsigned)m_det, j, md0);
+            md1 = tfx_writelane_i32((int)(unsigned)(m_det >> 32), j, md1);
+            mp0 = tfx_writelane_i32((int)(unsigned)m_pop, j, mp0);
+            mp1 = tfx_writelane_i32((int)(unsigned)(m_pop >> 32), j, mp1);
+            mf0 = tfx_writelane_i32((int)(unsigned)m_far, j, mf0);
+            mf1 = tfx_writelane_i32((int)(unsigned)(m_far >> 32), j, mf1);
+            // x of the last car after the move (junk, and unused, when the road is empty)
+            r_t = tfx_writelane_i32(__builtin_amdgcn_readlane(__float_as_int(xn), n_totj > 0 ? n_totj - 1 : 0), j, r_t);
+          }
+        }
+      }
+      {
+        // write the sub-tile back as it came: 16 B per lane, 1 KiB per wave instruction
+        __builtin_amdgcn_wave_barrier();
+        const float4 *src4 = reinterpret_cast<const float4 *>(buf);
+        float4 *dst4 = reinterpret_cast<float4 *>(tx + (size_t)j0 * C);
+        const int n16 = (ns * C) >> 1;
+        for (int q0 = 0; q0 < n16; q0 += 64) {
+          const int q = q0 + lane;
+          if (q < n16) dst4[q] = src4[q];
+        }
+      }
+    }
+
+    // ================= phase W: lane j finishes road j ==========================================
+    if (valid) {
+      const unsigned long long live = lane_mask_below(p.n_tot);
+      const unsigned long long m_pop = ((unsigned long long)(unsigned)mp1 << 32 | (unsigned)mp0) & live;
+      const unsigned long long m_wait = ((unsigned long long)(unsigned)mw1 << 32 | (unsigned)mw0) & live;
+      const unsigned long long m_det = ((unsigned long long)(unsigned)md1 << 32 | (unsigned)md0) & live;
+      const unsigned long long m_far = ((unsigned long long)(unsigned)mf1 << 32 | (unsigned)mf0) & m_pop;
+      // cars popped from the head: the while loop (:123) stops at the first car still on the road
+      const int kpop = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+      if (e < d.r) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (p.n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += __popcll(m_wait);
+          ob[d.r + e] = __popcll(m_det);
+        }
+        ob[e] = kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+      }
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, r_t, p.n_tot);
+      if (needs_serial(kpop, m_far != 0ull, p.n_tot, C)) d.env_flag[env] = tick + 1;
+      // the leader's x stays in its slot (after the write-back of the image, same wave)
+      d.xv[(size_t)id * C + p.ld].x = p.xL;
+      my_updates += (unsigned long long)p.n_tot;
+    }
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+}  // namespace tfx

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib",
 
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE = 0, 1, 2
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class TfxConfig(C.Structure):
@@ -24,7 +24,7 @@ class TfxConfig(C.Structure):
 
 
 class TfxBuffers(C.Structure):
-    _fields_ = [("state", C.c_void_p), ("leading", C.c_void_p), ("lastcar", C.c_void_p),
+    _fields_ = [("xv", C.c_void_p), ("w", C.c_void_p), ("leading", C.c_void_p), ("lastcar", C.c_void_p),
                 ("obs", C.c_void_p), ("rewards", C.c_void_p), ("waiting", C.c_void_p),
                 ("passed_dst", C.c_void_p), ("done_tick", C.c_void_p),
                 ("trip_times", C.c_void_p), ("n_trips", C.c_void_p), ("trip_cap", C.c_int32)]

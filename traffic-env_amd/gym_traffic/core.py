@@ -6,8 +6,9 @@ HIP kernels through the C ABI (include/tfx.h, csrc/tfx_hip.hip).  Both front-end
 (tensors in / tensors out for batched RL rollouts).
 
 State layout = the reference's arrays with a leading env dimension (traffic_env.py:361-382):
-    state [E,R,P,C] f32 (P planes: x, v[, w])   leading/lastcar [E,R] i32   obs [E,2r+2I] i32
-    rewards [E,I] f32   waiting [E,r] i32   passed_dst [E,I] u8   done_tick [E] i32
+    xv [E,R,C,2] f32 ((x, v) per ring slot; `x`/`v` are views)   w [E,R,C] f32 (planes == 3 only)
+    leading/lastcar [E,R] i32   obs [E,2r+2I] i32   rewards [E,I] f32   waiting [E,r] i32
+    passed_dst [E,I] u8   done_tick [E] i32
 """
 import ctypes as C
 
@@ -69,7 +70,9 @@ class TfxEngine(object):
         dev = self.device
         # zeros, not empty: the reference leaves these to np.empty garbage; a defined start keeps
         # runs reproducible (dead slots are never read)
-        self.state = torch.zeros((E, R, P, Cc), dtype=torch.float32, device=dev)
+        self.xv = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
+        self.x, self.v = self.xv[..., 0], self.xv[..., 1]
+        self.w = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
         self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.obs = torch.zeros((E, self.obs_len), dtype=torch.int32, device=dev)
@@ -83,7 +86,8 @@ class TfxEngine(object):
         self.n_trips = torch.zeros((E,), dtype=torch.int32, device=dev) if validate else None
         self._cars = torch.zeros((E, R), dtype=torch.int32, device=dev)
         b = nat.TfxBuffers()
-        b.state, b.leading, b.lastcar = _ptr(self.state), _ptr(self.leading), _ptr(self.lastcar)
+        b.xv, b.w = _ptr(self.xv), _ptr(self.w)
+        b.leading, b.lastcar = _ptr(self.leading), _ptr(self.lastcar)
         b.obs, b.rewards, b.waiting = _ptr(self.obs), _ptr(self.rewards), _ptr(self.waiting)
         b.passed_dst, b.done_tick = _ptr(self.passed_dst), _ptr(self.done_tick)
         b.trip_times, b.n_trips, b.trip_cap = _ptr(self.trip_times), _ptr(self.n_trips), self.trip_cap
@@ -214,13 +218,20 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_launch_info(self.h, *[C.byref(x) for x in v]))
         return dict(grid=v[0].value, block=v[1].value, waves_per_road=v[2].value)
 
+    def planes_numpy(self):
+        """(x, v, w) as NumPy [E,R,C] copies (w is zeros when it is not carried)."""
+        x = self.x.cpu().numpy()
+        v = self.v.cpu().numpy()
+        w = self.w.cpu().numpy() if self.w is not None else np.zeros_like(x)
+        return x, v, w
+
     # ---- bulk state import (tests, checkpoint restore) ----------------------------------------
     def load_state(self, x, v, leading, lastcar, w=None):
         """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
-        self.state[:, :, 0, :] = torch.as_tensor(np.asarray(x, np.float32)).to(self.device)
-        self.state[:, :, 1, :] = torch.as_tensor(np.asarray(v, np.float32)).to(self.device)
-        if self.P == 3 and w is not None:
-            self.state[:, :, 2, :] = torch.as_tensor(np.asarray(w, np.float32)).to(self.device)
+        self.x.copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
+        self.v.copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
+        if self.w is not None and w is not None:
+            self.w.copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
         self.leading.copy_(torch.as_tensor(np.asarray(leading, np.int32)).to(self.device))
         self.lastcar.copy_(torch.as_tensor(np.asarray(lastcar, np.int32)).to(self.device))
         self.refresh()

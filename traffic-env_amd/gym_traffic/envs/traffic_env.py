@@ -102,6 +102,32 @@ class DeviceView(object):
         return "DeviceView(%r)" % (self.numpy(),)
 
 
+class StateView(DeviceView):
+    """env.state as the reference shapes it: float32 [R, 3, C] with planes (x, v, w).  Reads gather
+    the planes from the device; `state[...] = value` writes them back and refreshes the engine."""
+
+    def __init__(self, eng):
+        self._eng = eng
+
+    def numpy(self):
+        x, v, w = self._eng.planes_numpy()
+        return np.stack([x[0], v[0], w[0]], axis=1)
+
+    def __setitem__(self, idx, value):
+        a = self.numpy()
+        a[idx] = value
+        eng = self._eng
+        eng.load_state(a[None, :, 0, :], a[None, :, 1, :], eng.leading.cpu().numpy(),
+                       eng.lastcar.cpu().numpy(), w=a[None, :, 2, :])
+
+    def __len__(self):
+        return self._eng.R
+
+    @property
+    def shape(self):
+        return (self._eng.R, 3, self._eng.C)
+
+
 class TrafficEnv(gym.Env):
     metadata = {'render.modes': ['human', 'rgb_array']}
 
@@ -145,7 +171,8 @@ class TrafficEnv(gym.Env):
                                 device=self.device)
         self._built = (float(FLAGS.rate), bool(flag('learn_switch', False)), self._validate, self._spec)
         eng = self.engine
-        self.state = DeviceView(lambda: eng.state[0], eng.refresh)            # [R, 3, C]: x, v, w planes
+        # [R, 3, C] = the reference's state[:, (xi, vi, wi), :]; a read assembles it from the device
+        self.state = StateView(eng)
         self.leading = DeviceView(lambda: eng.leading[0], eng.refresh)
         self.lastcar = DeviceView(lambda: eng.lastcar[0], eng.refresh)
         self.waiting = DeviceView(lambda: eng.waiting[0])
@@ -161,13 +188,13 @@ class TrafficEnv(gym.Env):
         if now == self._built:
             return
         old = self.engine
-        snap = [t.clone() for t in (old.state, old.leading, old.lastcar, old.obs, old.rewards,
+        snap = [t.clone() for t in (old.xv, old.w, old.leading, old.lastcar, old.obs, old.rewards,
                                     old.waiting, old.passed_dst)]
         tick = old.tick
         self._validate = now[2]
         self._build_engine()
         eng = self.engine
-        for dst, src in zip((eng.state, eng.leading, eng.lastcar, eng.obs, eng.rewards, eng.waiting,
+        for dst, src in zip((eng.xv, eng.w, eng.leading, eng.lastcar, eng.obs, eng.rewards, eng.waiting,
                              eng.passed_dst), snap):
             dst.copy_(src)
         eng.refresh()
@@ -259,7 +286,7 @@ class TrafficEnv(gym.Env):
         if self.viewer is None:
             self.viewer = MatplotlibViewer(self.graph)
         eng = self.engine
-        frame = self.viewer.draw(self.graph, eng.state[0].cpu().numpy(), eng.leading[0].cpu().numpy(),
+        frame = self.viewer.draw(self.graph, self.state.numpy(), eng.leading[0].cpu().numpy(),
                                  eng.lastcar[0].cpu().numpy(), self.current_phase, self.elapsed,
                                  YELLOW_TICKS, float(archetypes[0, li]), mode)
         if mode == 'human':

@@ -81,8 +81,8 @@ def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2):
     eng.reset(np.zeros((1, eng.I), np.int32))
     x, v, leading, lastcar = prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
     dev = eng.device
-    eng.state[:, :, 0, :] = torch.as_tensor(x).to(dev)[None]
-    eng.state[:, :, 1, :] = torch.as_tensor(v).to(dev)[None]
+    eng.x.copy_(torch.as_tensor(x).to(dev)[None].expand_as(eng.x))
+    eng.v.copy_(torch.as_tensor(v).to(dev)[None].expand_as(eng.v))
     eng.leading[:] = torch.as_tensor(leading).to(dev)[None]
     eng.lastcar[:] = torch.as_tensor(lastcar).to(dev)[None]
     eng.refresh()

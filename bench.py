@@ -32,17 +32,30 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICRO
 GATHER_EVERY = 10           # ticks between (obs, reward, done) snapshots to rank 0 (one agent step)
 
 
-def cpu_baseline(name, budget_s=12.0, max_ticks=60):
-    """Time the oracle on a bounded sample of the same workload: envs = 2 per host thread (at most
-    64), same prefill / spawn / light rules, until `budget_s` seconds or `max_ticks` ticks."""
+def host_threads():
+    """Threads this process may really use: the affinity mask, capped by the cgroup CPU quota (the
+    GPU boxes expose every core of the host but grant a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
+    """Time the oracle on a bounded sample of the same workload: 8 envs per host thread (at most
+    256), same prefill / spawn / light rules, for about `budget_s` seconds."""
     import numpy as np
     from gym_traffic import workload as wl
-    from oracle.oracle import OracleEnv, ARCHETYPE, live_mask
+    from oracle.oracle import OracleEnv
     from gym_traffic.envs.roadgraph import GridRoad
 
     c = wl.CONFIGS[name]
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    envs = max(1, min(64, 2 * threads, c["envs"]))
+    threads = host_threads()
+    envs = max(1, min(256, 8 * threads, c["envs"]))
     g = GridRoad(c["m"], c["n"], c["length"])
     g.generate_entrypoints(0)
     orc = OracleEnv(c["m"], c["n"], c["length"], c["capacity"], g.dest, g.phases, g.nexts, n_envs=envs)
@@ -52,25 +65,29 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=60):
     for k in range(envs):
         orc.load_planes(k, x, v, w, leading, lastcar)
     env_ids = np.arange(envs)
+    # the spawn rule has period SPAWN_PERIOD, the light rule 2*LIGHT_PERIOD: build one period of
+    # schedules up front so that only the oracle's C code is inside the timed loop
+    period = int(np.lcm(wl.SPAWN_PERIOD, 2 * wl.LIGHT_PERIOD))
     sched = []
-    for t in range(max_ticks):
+    for t in range(period):
         roads = np.asarray(wl.spawn_roads_for_tick(g.entrypoints, t), np.int32)
         off = np.arange(envs + 1, dtype=np.int64) * len(roads)
         sched.append((wl.cycle_actions(env_ids, orc.I, t), (off, np.tile(roads, envs))))
-    orc.step(*sched[0], nthreads=threads)            # warm the code and the caches
+    for t in range(3):                                   # warm the code and the caches
+        orc.step(*sched[t], nthreads=threads)
     base = orc.vehicle_updates
     t0 = time.perf_counter()
     ticks = 0
-    for t in range(1, max_ticks):
-        orc.step(*sched[t], nthreads=threads)
+    for t in range(3, max_ticks):
+        orc.step(*sched[t % period], nthreads=threads)
         ticks += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
     updates = orc.vehicle_updates - base
     return {"value": updates / dt, "unit": "vehicle-updates/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d ticks of %s (%.3g vehicle-updates in %.1f s), OpenMP over envs, "
-                      "oracle/idm_oracle.c" % (envs, ticks, name, updates, dt)}
+            "sample": "%d envs x %d ticks of %s (%.3g vehicle-updates in %.1f s), OpenMP over envs "
+                      "on %d threads, oracle/idm_oracle.c" % (envs, ticks, name, updates, dt, threads)}
 
 
 def load_pmc_traffic(name):

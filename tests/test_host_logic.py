@@ -1,0 +1,169 @@
+"""CPU-side tests of the host logic that surrounds the GPU step: road tables, entry points, the
+seeded spawn schedules (must equal the reference's, car for car), GSpace, the gym protocol shim,
+flags, the synthetic workload recipe and render geometry.  No GPU, no oracle on the product path."""
+import numpy as np
+import pytest
+
+from conftest import golden_names
+
+import gym_traffic  # noqa: F401  (installs the gym shim when gym is absent, registers traffic-v0)
+import gym
+from gym_traffic.envs.roadgraph import GridRoad
+from gym_traffic.spaces.gspace import GSpace
+from gym_traffic.spawner import SpawnSchedule, counts_from_roads
+from gym_traffic import workload as wl
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_gridroad_tables_and_spawn_schedule_match_reference(name, golden_cache):
+    g = golden_cache(name)
+    sc = g.sc
+    gr = GridRoad(sc["m"], sc["n"], sc["L"])
+    spec = 0b1110 if sc["entry"] == "one" else 0
+    gr.generate_entrypoints(spec)
+    assert np.array_equal(gr.nexts, g["nexts"])
+    assert np.array_equal(gr.dest, g["dest"])
+    assert np.array_equal(gr.phases, g["phases"])
+    assert np.array_equal(gr.entrypoints, g["entrypoints"])
+    assert gr.roads == len(g["nexts"]) and gr.train_roads == 4 * sc["m"] * sc["n"]
+    # reset_entrypoints: cars_per_sec = local * m * open sides (traffic_env.py:394)
+    cps = sc["lcps"] * sc["m"] * (4 - bin(spec).count("1"))
+    assert cps == float(g["cars_per_sec"])
+    s = SpawnSchedule(np.random.RandomState(sc["seed"]), sc["poisson"], gr.entrypoints, lambda: (cps, sc["rate"]))
+    n = 0
+    for t in range(sc["T"]):
+        got = s.next_tick()
+        assert got == g.spawns(t).tolist(), (name, t)
+        n += len(got)
+    assert n == int(g["generated_cars"])
+
+
+def test_gridroad_structure():
+    gr = GridRoad(3, 4, 100)
+    R, r = gr.roads, gr.train_roads
+    assert (R, r, gr.intersections) == (4 * 12 + 2 * 3 + 2 * 4, 48, 12)
+    # every non-entry road has exactly one predecessor; exits have none downstream
+    nx = gr.nexts
+    assert np.all(nx[r:] == -1) and np.all(nx[:r] >= 0)
+    targets = nx[:r]
+    assert len(set(targets.tolist())) == r                      # one producer per road
+    gr.generate_entrypoints(0)
+    assert set(range(R)) - set(targets.tolist()) == set(gr.entrypoints.tolist())
+    assert gr.locs.shape == (R, 2, 2) and gr.locs.dtype == np.float32
+    # a road's end is its successor's start (up to the lane offset eps)
+    for e in range(r):
+        assert np.abs(gr.locs[e, 1] - gr.locs[nx[e], 0]).max() <= 0.05 * 100
+
+
+def test_entry_spec_bits():
+    gr = GridRoad(2, 3, 50)
+    v = 6
+    assert gr.generate_entrypoints(0b1110).tolist() == [0, 3]                       # west side only
+    assert gr.generate_entrypoints(0b1101).tolist() == [v + 2, v + 5]               # east side only
+    assert gr.generate_entrypoints(0b1011).tolist() == [2 * v, 2 * v + 1, 2 * v + 2]
+    assert gr.generate_entrypoints(0b0111).tolist() == [3 * v + 3, 3 * v + 4, 3 * v + 5]
+    assert gr.generate_entrypoints(0b1111).size == 0
+
+
+def test_gspace_surface():
+    sp = GSpace([4], np.int32(2))
+    assert sp.size == 4 and sp.shape == [4] and sp.limit.dtype == np.int32
+    np.random.seed(3)
+    a = sp.sample()
+    np.random.seed(3)
+    assert np.array_equal(a, np.random.randint(np.int32(2), size=[4], dtype=np.int32))
+    assert sp.empty().shape == (4,) and sp.empty().dtype == np.int32
+    assert sp.to_action(np.array([[True, False], [False, True]])).tolist() == [1, 0, 0, 1]
+    rep = sp.replicated(3)
+    assert rep.shape == [3, 4] and rep.size == 12
+    assert GSpace([2, 3], np.float32(1)).empty().dtype == np.float32
+
+
+def test_gym_protocol_and_registration():
+    class Dummy(gym.Env):
+        def __init__(self):
+            self.action_space = GSpace([2], np.int32(2))
+            self.observation_space = GSpace([3], np.int32(1))
+            self.reward_size = 2
+            self.renders = 0
+
+        def _step(self, a):
+            return np.zeros(3), np.ones(2), False, None
+
+        def _reset(self):
+            return np.zeros(3)
+
+        def _render(self, mode='human', close=False):
+            self.renders += 1
+
+    env = Dummy()
+    assert env.unwrapped is env
+    env.step(0)
+    assert env.renders == 0
+    env.rendering = True                     # render-every-inner-step switch (reference __init__.py:6-10)
+    env.step(0)
+    assert env.renders == 1
+
+    class Twice(gym.Wrapper):
+        def _step(self, a):
+            o, r, d, i = self.env.step(a)
+            return o, r * 2, d, i
+
+    w = Twice(env)
+    assert w.reward_size == 2 and w.unwrapped is env and w.action_space is env.action_space
+    assert w.step(0)[1].tolist() == [2, 2]
+    from gym.envs.registration import register  # noqa: F401
+    e = gym.make('traffic-v0')
+    assert type(e).__name__ == 'TrafficEnv' and e.graph is None
+
+
+def test_counts_from_roads():
+    idx = {5: 0, 9: 1, 2: 2}
+    assert counts_from_roads([9, 9, 2], idx, 3).tolist() == [0, 2, 1]
+
+
+def test_flags_defaults_and_update():
+    from gym_traffic.flags import FLAGS, flag, update_flags
+    assert flag('rate') == 0.5 and flag('poisson') is True and flag('entry') == 'all'
+    assert flag('no_such_flag', 7) == 7
+    update_flags(rate=0.25)
+    assert FLAGS.rate == 0.25
+    update_flags(rate=0.5)
+
+
+def test_workload_recipe():
+    c = wl.CONFIGS["cfg2"]
+    x, v, leading, lastcar = wl.prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
+    R = 4 * 256 + 64
+    assert x.shape == (R, 66) and (lastcar - leading == 48).all()
+    assert x[0, 2] == np.float32(392.0) and x[0, 49] == np.float32(400 - 8 * 48)
+    assert np.isinf(x[:, 1]).all()
+    assert (np.diff(x[:, 2:50], axis=1) < 0).all()               # head first, decreasing x
+    ns = slice(2 * 256, 4 * 256)
+    assert (v[ns, 2:6] == 0).all() and (v[ns, 7:50] == 8).all()    # red at t=0: stopped within 40 m
+    assert (v[:512, 2:50] == 8).all()
+    gr = GridRoad(16, 16, 400)
+    gr.generate_entrypoints(0)
+    per = [len(wl.spawn_roads_for_tick(gr.entrypoints, t)) for t in range(8)]
+    assert sum(per) == 64                                       # every entry road once per period
+    a = wl.cycle_actions(np.arange(40), 3, 5)
+    assert a.shape == (40, 3) and a[0].tolist() == [0, 0, 0] and a[15].tolist() == [1, 1, 1]
+    assert wl.algorithmic_bytes_per_tick(10, 2, 1) == 16 * 10 + 48 * 2 + 32
+
+
+def test_render_geometry():
+    from gym_traffic.render import light_colours, car_segments
+    gr = GridRoad(2, 2, 100)
+    cols = light_colours(gr, np.array([1, 0, 1, 0]), np.array([0, 9, 9, 0]), 6)
+    assert cols[0].tolist() == [1, 1, 0]        # road 0: phase 1 == current 1 (red side), fresh -> yellow
+    assert cols[1].tolist() == [0, 1, 0]        # phase 1 != 0, old -> green
+    assert cols[2].tolist() == [1, 0, 0]        # red and not fresh
+    assert cols[3].tolist() == [1, 0, 0]        # green side but fresh -> still red
+    state = np.zeros((gr.roads, 3, 6), np.float32)
+    leading = np.ones(gr.roads, np.int32)
+    lastcar = np.ones(gr.roads, np.int32)
+    state[0, 0, 2:4] = [60, 30]
+    lastcar[0] = 3
+    seg = car_segments(gr, state, leading, lastcar, 4.0)
+    assert seg.shape == (2, 4)
+    assert np.allclose(seg[0, 0] - seg[0, 2], 4.0) and np.allclose(seg[:, 1], seg[:, 3])

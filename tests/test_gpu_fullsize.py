@@ -1,0 +1,114 @@
+"""Headline-size (cfg2: 4096 envs x 16x16 x 64-car roads) properties that need no per-car
+reference: conservation of cars, sortedness, determinism (a race would show as drift between two
+runs), independence of an env from the batch it is in, agreement with the oracle on a sample of
+envs, and the same for the cfg4-shaped 2-wave-per-road kernel."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleEnv, live_mask
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from gym_traffic import workload as wl  # noqa: E402
+
+
+def oracle_for(eng, c, envs, first_env):
+    orc = OracleEnv(c["m"], c["n"], c["length"], c["capacity"], eng.dest, eng.phases, eng.nexts, n_envs=envs)
+    orc.reset(np.zeros(orc.I, np.int32))
+    x, v, leading, lastcar = wl.prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
+    for k in range(envs):
+        orc.load_planes(k, x, v, np.zeros_like(x), leading, lastcar)
+    return orc, np.arange(first_env, first_env + envs)
+
+
+def step_oracle(orc, ids, eng, t, threads=8):
+    roads = wl.spawn_roads_for_tick(eng.entrypoints, t)
+    return orc.step(wl.cycle_actions(ids, orc.I, t), [roads] * len(ids), nthreads=threads)
+
+
+def test_cfg2_full_size_properties():
+    c = wl.CONFIGS["cfg2"]
+    T = 45
+    eng = wl.setup_engine("cfg2")
+    E, R, C = eng.E, eng.R, eng.C
+    assert (E, R, C) == (4096, 1088, 66)
+    sample = [0, 1, 19, 20, 2047, 4095]                  # env ids checked against the oracle
+    orcs = [oracle_for(eng, c, 1, k) for k in sample]
+    small = wl.setup_engine("cfg2", envs=3, env_id_offset=19)   # global envs 19, 20, 21 in a tiny batch
+    cars = int(eng.cars_on_roads_flat().sum())
+    assert cars == E * R * 48
+    eng.reset_counters()
+    upd = 0
+    for t in range(T):
+        before = eng.cars_on_roads_flat().to(torch.int64).sum().item()
+        eng.step(1)
+        small.step(1)
+        for (orc, ids) in orcs:
+            step_oracle(orc, ids, eng, t, threads=1)
+        # conservation: cars after = cars before + accepted spawns - cars that left the map
+        after = eng.cars_on_roads_flat().to(torch.int64).sum().item()
+        spawned = len(wl.spawn_roads_for_tick(eng.entrypoints, t)) * E
+        assert after <= before + spawned
+        upd += before          # lower bound of the device counter (spawned cars add to it)
+    assert eng.vehicle_updates() >= upd
+    ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+    assert ld.min() >= 1 and lc.min() >= 1 and ld.max() <= C - 1 and lc.max() <= C - 1
+    # the six sampled envs equal the oracle bit for bit (ints + live x, v)
+    for (orc, ids), k in zip(orcs, sample):
+        assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), k
+        assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]), k
+        assert np.array_equal(eng.rewards[k].cpu().numpy(), orc.rewards[0]), k
+        live = live_mask(ld[k], lc[k], C)
+        xk, vk = eng.x[k].cpu().numpy(), eng.v[k].cpu().numpy()
+        assert np.array_equal(xk[live].view(np.int32), orc.x[0][live].view(np.int32)), k
+        assert np.array_equal(vk[live].view(np.int32), orc.v[0][live].view(np.int32)), k
+    # an env's trajectory does not depend on the batch it is stepped in
+    assert torch.equal(small.leading, eng.leading[19:22]) and torch.equal(small.obs, eng.obs[19:22])
+    # sortedness: x never increases from head to tail (checked on a slice of envs)
+    xs = eng.x[:64].cpu().numpy()
+    for k in range(0, 64, 9):
+        for e in range(0, R, 37):
+            s, order = int(ld[k, e]), []
+            while s != int(lc[k, e]):
+                s = s + 1 if s + 1 < C else 1
+                order.append(xs[k, e, s])
+            assert all(a >= b for a, b in zip(order, order[1:])), (k, e)
+
+
+def test_cfg2_determinism_two_runs():
+    a = wl.setup_engine("cfg2", envs=512)
+    b = wl.setup_engine("cfg2", envs=512)
+    a.step(60)
+    for _ in range(6):
+        b.step(10)
+    for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    ld, lc = a.leading.cpu().numpy(), a.lastcar.cpu().numpy()
+    xa, xb = a.xv.cpu().numpy(), b.xv.cpu().numpy()
+    for k in range(0, 512, 37):
+        live = live_mask(ld[k], lc[k], a.C)
+        assert np.array_equal(xa[k][live].view(np.int32), xb[k][live].view(np.int32))
+
+
+def test_cfg4_shape_two_waves_per_road_vs_oracle():
+    """64-wide rings do not fit one wavefront at 128 cars/road: cfg4's kernel (k_move<2>) on a
+    smaller grid with the same CAPACITY = 130, against the oracle."""
+    c = dict(wl.CONFIGS["cfg4"], m=4, n=4, envs=3)
+    wl.CONFIGS["_cfg4_small"] = c
+    try:
+        eng = wl.setup_engine("_cfg4_small")
+        orc, ids = oracle_for(eng, c, 3, 0)
+        for t in range(40):
+            eng.step(1)
+            step_oracle(orc, ids, eng, t, threads=3)
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        assert np.array_equal(ld, orc.leading) and np.array_equal(lc, orc.lastcar)
+        assert np.array_equal(eng.obs.cpu().numpy(), orc.obs)
+        x, v, _ = eng.planes_numpy()
+        for k in range(3):
+            live = live_mask(ld[k], lc[k], eng.C)
+            assert np.array_equal(x[k][live].view(np.int32), orc.x[k][live].view(np.int32))
+            assert np.array_equal(v[k][live].view(np.int32), orc.v[k][live].view(np.int32))
+    finally:
+        del wl.CONFIGS["_cfg4_small"]

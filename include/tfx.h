@@ -161,6 +161,11 @@ int tfx_reset_counters(tfx_handle h, void *stream);
  * tfx_profile_read waits for them and returns (and clears) the summed durations. 0 disables. */
 int tfx_profile(tfx_handle h, int32_t max_ticks);
 int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t *n_ticks);
+/* Two of the IDM's three divisions have a constant divisor (2*sqrt(a*b) and v0).  At tfx_create the
+ * library checks on the device, exhaustively over the admitted numerator range, that the
+ * reciprocal form it would like to use is bit-identical to IEEE division for these constants;
+ * `enabled` reports whether it is in use, `mismatches` the count found (0 when enabled). */
+int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches);
 /* launch geometry of the move kernel, for the roofline report */
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
 

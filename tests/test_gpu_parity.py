@@ -387,3 +387,11 @@ def test_vehicle_update_counter():
         expect += before + spawned
     assert eng.vehicle_updates() == expect
     assert expect > 500
+
+
+def test_reciprocal_division_selftest():
+    """The move kernel replaces two IEEE divisions by constant divisors with a reciprocal form only
+    after checking on the device, for every admitted numerator, that the quotient is bit-identical."""
+    eng = engine_for(dict(m=2, n=2, length=100.0, capacity=10, rate=0.5))
+    st = eng.fastdiv_status()
+    assert st["mismatches"] == 0 and st["enabled"]

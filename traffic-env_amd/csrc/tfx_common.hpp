@@ -23,6 +23,8 @@ struct Dev {
   int dbg;  // TFX_DEBUG ablation bits (timing experiments only; results are wrong when set)
   float length, rate, car_v, car_l, car_a, car_v0, car_b, car_T, car_s0;
   float two_sab, eps, thresh, near_end, ovf_pen;
+  float r_two_sab, r_v0;  // correctly rounded reciprocals of the two constant divisors
+  int fastdiv;            // the reciprocal form of those divisions was verified exact (div_selftest)
   // caller-owned state
   float2 *xv;  // [E][R][C] (x, v) per ring slot
   float *w;    // [E][R][C] spawn tick per ring slot, or nullptr
@@ -73,6 +75,45 @@ __device__ __forceinline__ void idm_step(const Dev &d, float x, float v, float x
   const float s_star = d.car_s0 + np_max0(t_gap + appr / d.two_sab);
   const float s = (xl - x) - ll;
   const float q = v / d.car_v0;
+  const float qd = pow4_cr(q);
+  const float u = s_star / (s + d.eps);
+  const float dv = d.car_a * ((1.0f - qd) - u * u);
+  const float dvr = dv * d.rate;
+  const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+  xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+  vn = np_max0(v + dvr);
+}
+
+// a / c for a constant c with rc = RN(1/c): q0 = RN(a*rc), r = a - q0*c (exact in one FMA),
+// q = RN(q0 + r*rc).  For the two constants of the IDM (2*sqrt(a*b) and v0) this equals the
+// correctly rounded quotient for EVERY numerator in the domain idm_fast_domain() admits - checked
+// exhaustively on the device for the handle's constants (k_div_selftest) before `fastdiv` is set.
+// Saves two v_rcp_f32 and ~14 VALU operations per car.
+__device__ __forceinline__ float div_const(float a, float c, float rc) {
+  const float q0 = a * rc;
+  const float r = __builtin_fmaf(-q0, c, a);
+  return __builtin_fmaf(r, rc, q0);
+}
+
+// v for which both constant-divisor quotients of idm_step are covered by the self-test: v == 0, or
+// 1e-10 <= v <= 1e18 (then appr = v*(v - vl) is 0 or 6e-28 <= |appr| <= 2e36 for any admitted vl).
+#define TFX_FASTDIV_V_LO 1e-10f
+#define TFX_FASTDIV_V_HI 1e18f
+#define TFX_FASTDIV_A_LO 5e-28f
+#define TFX_FASTDIV_A_HI 4e36f
+__device__ __forceinline__ bool idm_fast_domain(float v) {
+  return (v == 0.0f) || (v >= TFX_FASTDIV_V_LO && v <= TFX_FASTDIV_V_HI);
+}
+
+// idm_step with the two constant-divisor divisions in reciprocal form (bit-identical on the
+// admitted domain; callers check idm_fast_domain for every live lane first).
+__device__ __forceinline__ void idm_step_fast(const Dev &d, float x, float v, float xl, float vl, float ll,
+                                              float &xn, float &vn) {
+  const float t_gap = v * d.car_T;
+  const float appr = v * (v - vl);
+  const float s_star = d.car_s0 + np_max0(t_gap + div_const(appr, d.two_sab, d.r_two_sab));
+  const float s = (xl - x) - ll;
+  const float q = div_const(v, d.car_v0, d.r_v0);
   const float qd = pow4_cr(q);
   const float u = s_star / (s + d.eps);
   const float dv = d.car_a * ((1.0f - qd) - u * u);

@@ -66,6 +66,7 @@ struct tfx_handle_s {
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
   size_t move_lds = 0;
+  unsigned long long div_mismatches = 0;  // result of the reciprocal-division self-test
 };
 
 namespace {
@@ -130,9 +131,9 @@ int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds 
 }
 
 // k_move_dma<CC, S, NBUF, UNR, LEADER_LDS>: size the grid on first use, then launch
-template <int CC, int S, int NBUF, int UNR, bool LDSL>
+template <int CC, int S, int NBUF, int UNR, bool LDSL, int LIVE = 0>
 int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
-  auto kern = k_move_dma<CC, S, NBUF, UNR, LDSL>;
+  auto kern = k_move_dma<CC, S, NBUF, UNR, LDSL, LIVE>;
   if (h->grid_move == 0) {
     h->move_lds = (size_t)4 * NBUF * S * h->d.C * sizeof(float2);
     if (h->move_lds > 64 * 1024)
@@ -159,7 +160,7 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   const int C = h->d.C;
   const int v = h->move_variant;
   if ((C & 1) || v == 1) return launch_generic<1>(h, tidx, st);  // odd capacity: records not 16-B multiples
-  if (C == 34) return launch_dma<34, 8, 2, 8, false>(h, tidx, st);   // cfg1
+  if (C == 34) return launch_dma<34, 8, 2, 4, false, 2>(h, tidx, st);   // cfg1
   if (C != 66 || v == 26) return launch_dma<0, 8, 1, 8, false>(h, tidx, st);  // capacity read at run time
   switch (v) {  // C == 66 (cfg2): tuning points
     case 20: return launch_dma<66, 8, 1, 8, false>(h, tidx, st);
@@ -170,7 +171,14 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
     case 27: return launch_dma<66, 8, 2, 2, false>(h, tidx, st);
     case 28: return launch_dma<66, 16, 1, 8, false>(h, tidx, st);
     case 29: return launch_dma<66, 8, 2, 1, false>(h, tidx, st);
-    default: return launch_dma<66, 8, 2, 8, false>(h, tidx, st);
+    case 31: return launch_dma<66, 8, 2, 8, false, 1>(h, tidx, st);
+    case 32: return launch_dma<66, 8, 2, 8, false, 2>(h, tidx, st);
+    case 33: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);
+    case 34: return launch_dma<66, 8, 3, 8, false, 2>(h, tidx, st);
+    case 35: return launch_dma<66, 4, 3, 4, false, 2>(h, tidx, st);
+    case 36: return launch_dma<66, 4, 2, 4, false, 2>(h, tidx, st);
+    case 21: return launch_dma<66, 8, 2, 8, false>(h, tidx, st);
+    default: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);  // best measured
   }
 }
 
@@ -240,6 +248,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.car_b = cfg->car_b; d.car_T = cfg->car_T; d.car_s0 = cfg->car_s0;
   d.two_sab = 2.0f * sqrtf(cfg->car_a * cfg->car_b);  // 2 * np.sqrt(a*b) (traffic_env.py:54)
   d.eps = cfg->eps;
+  d.r_two_sab = 1.0f / d.two_sab;
+  d.r_v0 = 1.0f / cfg->car_v0;
   d.thresh = cfg->thresh;
   d.near_end = cfg->length - cfg->detect_dist;
   d.ovf_pen = cfg->overflow_penalty;
@@ -291,6 +301,23 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.veh = (unsigned long long *)(base + o_misc);
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
+  // reciprocal division is used only if it is exact for this handle's constants on the whole
+  // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
+  d.fastdiv = 0;
+  {
+    const char *fd = getenv("TFX_FASTDIV");
+    if (!fd || atoi(fd) != 0) {
+      unsigned long long *bad = d.veh;  // scratch word, zero at this point
+      hipLaunchKernelGGL(k_div_selftest, dim3(h->n_cu * 8), dim3(256), 0, 0, d.two_sab, d.r_two_sab,
+                         TFX_FASTDIV_A_LO, TFX_FASTDIV_A_HI, bad);
+      hipLaunchKernelGGL(k_div_selftest, dim3(h->n_cu * 8), dim3(256), 0, 0, cfg->car_v0, d.r_v0,
+                         TFX_FASTDIV_V_LO, TFX_FASTDIV_V_HI, bad);
+      unsigned long long nbad = 1;
+      if (hipMemcpy(&nbad, bad, sizeof nbad, hipMemcpyDeviceToHost) == hipSuccess && nbad == 0) d.fastdiv = 1;
+      (void)hipMemset(bad, 0, sizeof nbad);
+      h->div_mismatches = nbad;
+    }
+  }
   d.action_mode = TFX_ACTION_CYCLE;
   d.action_period = 20;
   d.spawn_mode = TFX_SPAWN_NONE;
@@ -521,6 +548,13 @@ int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t 
   if (advance_ms) *advance_ms = ad;
   if (n_ticks) *n_ticks = h->ev_used;
   h->ev_used = 0;
+  return TFX_OK;
+}
+
+int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (enabled) *enabled = h->d.fastdiv;
+  if (mismatches) *mismatches = h->div_mismatches;
   return TFX_OK;
 }
 

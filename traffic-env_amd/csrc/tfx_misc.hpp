@@ -79,4 +79,26 @@ __global__ void k_done(const Dev d, uint8_t *out, int since_tick) {
     out[env] = d.done_tick[env] > since_tick ? 1 : 0;
 }
 
+// Exhaustive check of div_const(a, c, rc) == a / c over every float a with lo <= |a| <= hi (both
+// signs) and a == +-0.  Signed zeros compare equal (the consumers add the quotient to another
+// value or raise it to the 4th power, so the sign of a zero quotient never survives).
+__global__ void k_div_selftest(float c, float rc, float lo, float hi, unsigned long long *mismatches) {
+  const unsigned lo_b = __float_as_uint(lo), hi_b = __float_as_uint(hi);
+  const unsigned long long n = (unsigned long long)(hi_b - lo_b) + 1ull;
+  unsigned long long bad = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n + 2;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    unsigned bits;
+    if (i < n) bits = lo_b + (unsigned)i;
+    else if (i < 2 * n) bits = (lo_b + (unsigned)(i - n)) | 0x80000000u;
+    else bits = (i == 2 * n) ? 0u : 0x80000000u;
+    const float a = __uint_as_float(bits);
+    const float want = a / c;
+    const float got = div_const(a, c, rc);
+    const bool same = (__float_as_uint(want) == __float_as_uint(got)) || (want == 0.0f && got == 0.0f);
+    bad += same ? 0 : 1;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace tfx

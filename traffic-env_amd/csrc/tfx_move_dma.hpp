@@ -22,6 +22,8 @@
 // CC = 0 reads it from the config (single-buffered only).  Needs an even capacity (16-byte road
 // records); otherwise the generic k_move<1> is used.
 #pragma once
+#include <type_traits>
+
 #include "tfx_common.hpp"
 
 namespace tfx {
@@ -46,9 +48,11 @@ __device__ __forceinline__ unsigned long long lane_mask_below(int n) {  // lanes
   return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
 
-template <int CC, int S, int NBUF, int UNR, bool LEADER_LDS>
+template <int CC, int S, int NBUF, int UNR, bool LEADER_LDS, int LIVE>
 __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
-  static_assert(NBUF == 1 || CC > 0, "double buffering needs a compile-time capacity");
+  static_assert(NBUF == 1 || CC > 0, "multi-buffering needs a compile-time capacity");
+  static_assert(NBUF >= 1 && NBUF <= 3, "1 to 3 LDS buffers");
+  static_assert(LIVE == 0 || CC > 0, "live-chunk streaming needs a compile-time capacity");
   constexpr int TR = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -81,6 +85,8 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     const int e = id - env * d.R;
     const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, valid, valid);
     const int pk = pack_desc(p.ld, p.lc, p.n_old, p.n_tot);
+    // roads of this tile that received cars this tick (bit j = road j), wave-uniform
+    const unsigned long long spawn_mask = __builtin_amdgcn_ballot_w64(valid && p.n_tot != p.n_old);
     const int xL_bits = __float_as_int(p.xL), xs0_bits = __float_as_int(p.xs0);
 
     // ================= phase C: sub-tiles of S roads through LDS =================================
@@ -90,102 +96,171 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     // road j's ballots, collected by lane j
     int mw0 = 0, mw1 = 0, md0 = 0, md1 = 0, mp0 = 0, mp1 = 0, mf0 = 0, mf1 = 0, r_t = 0;
 
-    auto issue = [&](int j0, float2 *dst) {
+    // LIVE > 0: only the 16-byte chunks (2 ring slots) that hold a live car are moved.  Bit i of
+    // the returned mask says whether this lane's chunk of DMA instruction i is live; the same mask
+    // drives the write-back (LIVE == 2).  Chunk q of a sub-tile belongs to road q / (C/2).
+    auto issue = [&](int j0, float2 *dst) -> unsigned {
       const int ns = (nroads - j0 < S) ? nroads - j0 : S;
       const float2 *gsrc = tx + (size_t)j0 * C;
       const int n16 = (ns * C) >> 1;  // 16-byte chunks
-      for (int q0 = 0; q0 < n16; q0 += 64) {
+      unsigned bits = 0;
+      int i = 0;
+      for (int q0 = 0; q0 < n16; q0 += 64, ++i) {
         const int q = q0 + lane;
-        if (q < n16)
+        bool go = q < n16;
+        if (LIVE) {
+          const int half = C >> 1;
+          const int jj = q / half;
+          const int s0 = 2 * (q - jj * half);                 // slots s0, s0 + 1
+          const int pkr = __shfl(pk, (j0 + jj) & 63, 64);
+          const int ldr = pkr & 511, nr = (int)((unsigned)pkr >> 25);
+          int p0 = s0 - ldr - 1;                              // ring position of slot s0 behind the leader
+          p0 += (p0 < 0) ? C - 1 : 0;
+          int p1 = s0 - ldr;
+          p1 += (p1 < 0) ? C - 1 : 0;
+          go = go && ((s0 > 0 && p0 < nr) || p1 < nr);
+          bits |= go ? (1u << i) : 0u;
+        }
+        if (go && !(d.dbg & 4))
           __builtin_amdgcn_global_load_lds((gptr_t *)(gsrc + (size_t)q * 2), (lptr_t *)(dst + (size_t)q0 * 2), 16, 0, 0);
       }
+      return bits;
     };
 
-    if (NBUF == 2) issue(0, bufs);
-    int sub = 0;
-    for (int j0 = 0; j0 < nroads; j0 += S, ++sub) {
+    // Prefetch distance D = NBUF - 1 sub-tiles.  live[k] = live-chunk mask of the sub-tile that
+    // sits in buffer k.
+    constexpr int D = NBUF - 1;
+    unsigned live[NBUF];
+#pragma unroll
+    for (int k = 0; k < NBUF; ++k) live[k] = 0;
+    const int nsub = (nroads + S - 1) / S;
+    const int nfull = nroads / S;  // sub-tiles 0 .. nfull-1 are full
+    if (D > 0) {
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (k < nsub) live[k] = issue(k * S, bufs + k * sub_slots);
+    }
+    int slotb = 0;  // buffer of the current sub-tile = sub % NBUF
+    for (int sub = 0; sub < nsub; ++sub) {
+      const int j0 = sub * S;
       const int ns = (nroads - j0 < S) ? nroads - j0 : S;
-      float2 *buf = bufs + (NBUF == 2 ? (sub & 1) * sub_slots : 0);
-      if (NBUF == 2) {
-        const int jn = j0 + S;
-        if (jn + S <= nroads) {
-          // a full next sub-tile: leave exactly its K_DMA loads in flight (+ the K_DMA write-back
-          // stores of the previous sub-tile, which are younger than the loads being waited for)
-          issue(jn, bufs + ((sub + 1) & 1) * sub_slots);
-          if (sub > 0) wait_vmcnt<2 * K_DMA>(); else wait_vmcnt<K_DMA>();
-        } else {
-          if (jn < nroads) issue(jn, bufs + ((sub + 1) & 1) * sub_slots);
-          wait_vmcnt<0>();
+      float2 *buf = bufs + slotb * sub_slots;
+      unsigned live_cur;
+      if (D > 0) {
+        const int nx = sub + D;                     // sub-tile to put in flight now
+        int nb = slotb + D;
+        nb -= (nb >= NBUF) ? NBUF : 0;
+        if (nx < nsub) {
+          const unsigned lv = issue(nx * S, bufs + nb * sub_slots);
+#pragma unroll
+          for (int k = 0; k < NBUF; ++k)
+            if (k == nb) live[k] = lv;
         }
+        // younger than the loads of `sub`: the D sub-tiles issued after it and, once the pipeline
+        // is full, the D write-backs in between - all of K_DMA instructions when the sub-tiles
+        // involved are full; otherwise drain
+        if (nx < nfull && sub >= D) wait_vmcnt<2 * D * K_DMA>();
+        else if (nx < nfull) wait_vmcnt<D * K_DMA>();
+        else wait_vmcnt<0>();
+        live_cur = 0;
+#pragma unroll
+        for (int k = 0; k < NBUF; ++k)
+          if (k == slotb) live_cur = live[k];
       } else {
-        issue(j0, buf);
+        live_cur = issue(j0, buf);
         wait_vmcnt<0>();
       }
+      slotb = (slotb + 1 >= NBUF) ? 0 : slotb + 1;
 
-      for (int jj0 = 0; jj0 < ns; jj0 += UNR) {
-#pragma unroll
-        for (int ju = 0; ju < UNR; ++ju) {
-          const int jj = jj0 + ju;
-          if (jj < ns) {
-            const int j = j0 + jj;
-            const int pkj = __builtin_amdgcn_readlane(pk, j);
-            const float xLj = __int_as_float(__builtin_amdgcn_readlane(xL_bits, j));
-            const int ldj = pkj & 511, lcj = (pkj >> 9) & 511, n_oldj = (pkj >> 18) & 127;
-            const int n_totj = (int)((unsigned)pkj >> 25);
-            float2 *rb = buf + jj * C;  // this road's record in LDS
-            // ring slot of car `lane`: positions run 0 .. C-2 from slot 1
-            const unsigned pos = (unsigned)(ldj + lane);               // (ld - 1) + (lane + 1)
-            const unsigned slot = 1u + min(pos, pos - (unsigned)(C - 1));
-            const bool in_img = all_slots || lane < C - 1;
-            const unsigned sl = in_img ? slot : 1u;
-            const float2 cv = rb[sl];
-            float x = cv.x, v = cv.y;
-            if (n_totj != n_oldj) {  // wave-uniform: cars spawned this tick are not in memory yet
-              if (lane >= n_oldj && lane < n_totj) {
-                x = spawned_x(d, __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j)), lane - n_oldj);
-                v = d.car_v;
-              }
-            }
-            float xl, vl;
-            if (LEADER_LDS && n_totj == n_oldj) {
-              // the car one ring slot ahead in the image; lane 0's leader is the fake one
-              const unsigned prev = (sl == 1u) ? (unsigned)(C - 1) : sl - 1u;
-              const float2 lv = rb[prev];
-              xl = (lane == 0) ? xLj : lv.x;
-              vl = (lane == 0) ? 0.0f : lv.y;
-            } else {
-              // wave_shr:1 - lane k receives lane k-1; lane 0 keeps `old` = the fake leader
-              xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xLj), __float_as_int(x), 0x138, 0xf, 0xf, false));
-              vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
-            }
+      if (d.dbg & 8) continue;  // ablation: DMA (and phases M, W) only
 
-            float xn, vn;
-            idm_step(d, x, v, xl, vl, ll, xn, vn);
-
-            // new state back into the image: lanes without a car rewrite dead slots with junk,
-            // which nothing reads (the 64 lanes cover every ring slot except `leading`)
-            if (in_img) rb[sl] = make_float2(xn, vn);
-            if (n_totj != n_oldj && d.w) {
-              if (lane >= n_oldj && lane < n_totj) d.w[(size_t)base * C + j * C + slot] = (float)tick;
-            }
-            // wrapped ring: the reference tests x, not v, on the second segment (:210)
-            const unsigned lc_seg2 = (ldj > lcj) ? (unsigned)lcj : 0u;
-            const float wq = (slot <= lc_seg2) ? xn : vn;
-            const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(wq < d.thresh);
-            const unsigned long long m_det = __builtin_amdgcn_ballot_w64(xn > d.near_end);
-            const unsigned long long m_pop = __builtin_amdgcn_ballot_w64(xn > d.length);
-            const unsigned long long m_far = __builtin_amdgcn_ballot_w64((xn - d.length) > d.length);
-            mw0 = tfx_writelane_i32((int)(unsigned)m_wait, j, mw0);
-            mw1 = tfx_writelane_i32((int)(unsigned)(m_wait >> 32), j, mw1);
-            md0 = tfx_writelane_i32((int)(unsigned)m_det, j, md0);
-            md1 = tfx_writelane_i32((int)(unsigned)(m_det >> 32), j, md1);
-            mp0 = tfx_writelane_i32((int)(unsigned)m_pop, j, mp0);
-            mp1 = tfx_writelane_i32((int)(unsigned)(m_pop >> 32), j, mp1);
-            mf0 = tfx_writelane_i32((int)(unsigned)m_far, j, mf0);
-            mf1 = tfx_writelane_i32((int)(unsigned)(m_far >> 32), j, mf1);
-            // x of the last car after the move (junk, and unused, when the road is empty)
-            r_t = tfx_writelane_i32(__builtin_amdgcn_readlane(__float_as_int(xn), n_totj > 0 ? n_totj - 1 : 0), j, r_t);
+      // One road: lane k <-> the k-th car behind the fake leader.  SPAWN = false is the common case
+      // (no car entered this road this tick): straight-line code, so the unrolled bodies of a
+      // sub-tile form one basic block and the compiler interleaves independent roads.
+      auto road = [&](int jj, auto spawn_tag) {
+        constexpr bool SPAWN = decltype(spawn_tag)::value;
+        const int j = j0 + jj;
+        const int pkj = __builtin_amdgcn_readlane(pk, j);
+        const float xLj = __int_as_float(__builtin_amdgcn_readlane(xL_bits, j));
+        const int ldj = pkj & 511, lcj = (pkj >> 9) & 511, n_oldj = (pkj >> 18) & 127;
+        const int n_totj = (int)((unsigned)pkj >> 25);
+        float2 *rb = buf + jj * C;  // this road's record in LDS
+        // ring slot of car `lane`: positions run 0 .. C-2 from slot 1
+        const unsigned pos = (unsigned)(ldj + lane);  // (ld - 1) + (lane + 1)
+        const unsigned slot = 1u + min(pos, pos - (unsigned)(C - 1));
+        const bool in_img = all_slots || lane < C - 1;
+        const unsigned sl = in_img ? slot : 1u;
+        const float2 cv = rb[sl];
+        float x = cv.x, v = cv.y;
+        if (SPAWN) {  // cars spawned this tick are not in memory yet
+          if (lane >= n_oldj && lane < n_totj) {
+            x = spawned_x(d, __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j)), lane - n_oldj);
+            v = d.car_v;
           }
+        }
+        float xl, vl;
+        if (LEADER_LDS && !SPAWN) {
+          // the car one ring slot ahead in the image; lane 0's leader is the fake one
+          const unsigned prev = (sl == 1u) ? (unsigned)(C - 1) : sl - 1u;
+          const float2 lv = rb[prev];
+          xl = (lane == 0) ? xLj : lv.x;
+          vl = (lane == 0) ? 0.0f : lv.y;
+        } else {
+          // wave_shr:1 - lane k receives lane k-1; lane 0 keeps `old` = the fake leader
+          xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xLj), __float_as_int(x), 0x138, 0xf, 0xf, false));
+          vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+        }
+
+        float xn, vn;
+        // the reciprocal form of the two constant-divisor divisions is exact on a verified domain;
+        // one live car outside it (denormal-range or non-finite speed) sends the road down the
+        // IEEE-divide path.  Wave-uniform branch.
+        const unsigned long long off_domain =
+            __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) & lane_mask_below(n_totj);
+        if (d.dbg & 2) {  // ablation: no IDM arithmetic
+          xn = x + (xl - ll);
+          vn = v + vl;
+        } else if (d.fastdiv && off_domain == 0ull) {
+          idm_step_fast(d, x, v, xl, vl, ll, xn, vn);
+        } else {
+          idm_step(d, x, v, xl, vl, ll, xn, vn);
+        }
+
+        // new state back into the image: lanes without a car rewrite dead slots with junk,
+        // which nothing reads (the 64 lanes cover every ring slot except `leading`)
+        if (in_img) rb[sl] = make_float2(xn, vn);
+        if (SPAWN && d.w) {
+          if (lane >= n_oldj && lane < n_totj) d.w[(size_t)base * C + j * C + slot] = (float)tick;
+        }
+        // wrapped ring: the reference tests x, not v, on the second segment (:210)
+        const unsigned lc_seg2 = (ldj > lcj) ? (unsigned)lcj : 0u;
+        const float wq = (slot <= lc_seg2) ? xn : vn;
+        const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(wq < d.thresh);
+        const unsigned long long m_det = __builtin_amdgcn_ballot_w64(xn > d.near_end);
+        const unsigned long long m_pop = __builtin_amdgcn_ballot_w64(xn > d.length);
+        const unsigned long long m_far = __builtin_amdgcn_ballot_w64((xn - d.length) > d.length);
+        mw0 = tfx_writelane_i32((int)(unsigned)m_wait, j, mw0);
+        mw1 = tfx_writelane_i32((int)(unsigned)(m_wait >> 32), j, mw1);
+        md0 = tfx_writelane_i32((int)(unsigned)m_det, j, md0);
+        md1 = tfx_writelane_i32((int)(unsigned)(m_det >> 32), j, md1);
+        mp0 = tfx_writelane_i32((int)(unsigned)m_pop, j, mp0);
+        mp1 = tfx_writelane_i32((int)(unsigned)(m_pop >> 32), j, mp1);
+        mf0 = tfx_writelane_i32((int)(unsigned)m_far, j, mf0);
+        mf1 = tfx_writelane_i32((int)(unsigned)(m_far >> 32), j, mf1);
+        // x of the last car after the move (junk, and unused, when the road is empty)
+        r_t = tfx_writelane_i32(__builtin_amdgcn_readlane(__float_as_int(xn), n_totj > 0 ? n_totj - 1 : 0), j, r_t);
+      };
+
+      const unsigned long long sub_spawn = (spawn_mask >> j0) & ((1ull << S) - 1ull);
+      if (ns == S && sub_spawn == 0ull) {
+        for (int jj0 = 0; jj0 < S; jj0 += UNR) {
+#pragma unroll
+          for (int ju = 0; ju < UNR; ++ju) road(jj0 + ju, std::false_type{});
+        }
+      } else {
+        for (int jj = 0; jj < ns; ++jj) {
+          if ((sub_spawn >> jj) & 1ull) road(jj, std::true_type{});
+          else road(jj, std::false_type{});
         }
       }
       {
@@ -194,9 +269,10 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
         const float4 *src4 = reinterpret_cast<const float4 *>(buf);
         float4 *dst4 = reinterpret_cast<float4 *>(tx + (size_t)j0 * C);
         const int n16 = (ns * C) >> 1;
-        for (int q0 = 0; q0 < n16; q0 += 64) {
+        int i = 0;
+        for (int q0 = 0; q0 < n16; q0 += 64, ++i) {
           const int q = q0 + lane;
-          if (q < n16) dst4[q] = src4[q];
+          if (q < n16 && (LIVE < 2 || ((live_cur >> i) & 1u)) && !(d.dbg & 1)) dst4[q] = src4[q];
         }
       }
     }

@@ -60,6 +60,7 @@ _PROTOS = {
     "tfx_reset_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "tfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "tfx_fastdiv_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "tfx_launch_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 3),
 }
 

@@ -213,6 +213,11 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_profile_read(self.h, C.byref(mv), C.byref(ad), C.byref(n)))
         return dict(move_ms=mv.value, advance_ms=ad.value, ticks=n.value)
 
+    def fastdiv_status(self):
+        en, bad = C.c_int32(), C.c_uint64()
+        nat.check(self.lib.tfx_fastdiv_status(self.h, C.byref(en), C.byref(bad)))
+        return dict(enabled=bool(en.value), mismatches=int(bad.value))
+
     def launch_info(self):
         v = [C.c_int32() for _ in range(3)]
         nat.check(self.lib.tfx_launch_info(self.h, *[C.byref(x) for x in v]))

@@ -144,6 +144,17 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream);
 int tfx_move_cars(tfx_handle h, void *stream);
 int tfx_advance_finished_cars(tfx_handle h, void *stream);
 
+/* One agent decision = the Repeater (+ Remi) wrappers of traffic_test.py:27-64 fused on the device:
+ * n_ticks x _step with the held action; `passed` accumulates, `detected` keeps the last tick, an
+ * env that overflows stops for the rest of the step (`if done: break`); then, with remi != 0,
+ * remi_reward() (else the rewards are the sum over the ticks).  Outputs (device pointers, any may
+ * be NULL): aobs float32 [E][2r+I] = [sum passed | last detected | elapsed/100*(2*phase-1)],
+ * areward float32 [E][I], adone uint8 [E].  The launch sequence is captured into a HIP graph on
+ * first use and replayed afterwards.  Needs actions and spawns that do not change per tick on the
+ * host (one held action buffer or the cycle rule; no spawns, the periodic rule, or one count buffer). */
+int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
+                   uint8_t *adone, void *stream);
+
 /* remi (traffic_env.py:64-78) via TrafficEnv.remi_reward (:384-387) */
 int tfx_remi(tfx_handle h, void *stream);
 /* cars_on_roads (traffic_env.py:214-218): out device int32 [E][R] */

@@ -85,12 +85,13 @@ __device__ __forceinline__ int advance_road(const Dev &d, int env, int e, int ti
 
 // Literal single-thread advance for one env (taken when a road popped more than TFX_KP cars or a
 // handed-off car could itself be popped again this tick).  Follows :117-157 line by line.
-__device__ void advance_env_serial(const Dev &d, int env, int tick) {
+__device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
   const int C = d.C;
   int *ob = d.obs + (size_t)env * d.obs_len;
   float *rew = d.rewards + (size_t)env * d.I;
   int overflowed = 0;
-  for (int i = 0; i < d.I; ++i) rew[i] = 0.0f;
+  if (!(d.accum_rewards && tidx > 0))
+    for (int i = 0; i < d.I; ++i) rew[i] = 0.0f;
   for (int e = 0; e < d.R; ++e) {
     const int sp = d.rec[env * d.R + e].y;  // spawn overflows happened before move_cars
     if (sp > 0) {
@@ -99,7 +100,10 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick) {
         for (int j = 0; j < sp; ++j) rew[e % d.I] -= d.ovf_pen;
     }
   }
-  for (int e = 0; e < d.r; ++e) ob[e] = 0;
+  if (!(d.agent_mode && tidx > 0))
+    for (int e = 0; e < d.r; ++e) ob[e] = 0;
+  else  // k_move already added this tick's pops of the parallel form: take them back out
+    for (int e = 0; e < d.r; ++e) ob[e] -= rec_kpop(d.rec[env * d.R + e].x);
   for (int e = 0; e < d.R; ++e) {
     const int id = env * d.R + e;
     float2 *rx = d.xv + (size_t)id * C;
@@ -153,8 +157,10 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
     const int s = (int)(gid - (long)env * per_env);
+    if (gid == 0) *d.tickA = tick + 1;
+    if (env_frozen(d, env, tick)) continue;  // stopped for the rest of this agent step
     const bool serial = d.env_flag[env] == tick + 1;
-    if (serial && s == 0) advance_env_serial(d, env, tick);
+    if (serial && s == 0) advance_env_serial(d, env, tick, tidx);
     if (s < d.I) {
       // intersection s: its four incoming roads s, I+s, 2I+s, 3I+s (roadgraph.py:38-39)
       int ph_new, el_new;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
           ovf += advance_road(d, env, e, tick, tidx) + d.rec[env * d.R + e].y;
         }
         // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
-        float rw = 0.0f;
+        float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
         for (int j = 0; j < ovf; ++j) rw -= d.ovf_pen;
         d.rewards[(size_t)env * d.I + s] = rw;
         if (ovf > 0) d.done_tick[env] = tick + 1;
@@ -197,7 +203,6 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
         d.n_trips[env] = t;
       }
     }
-    if (gid == 0) *d.tickA = tick + 1;
   }
 }
 

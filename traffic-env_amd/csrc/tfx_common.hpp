@@ -21,6 +21,11 @@ struct Dev {
   int I, r, R, C, E, n_entry, obs_len;
   int yellow, learn_switch, validate, env_off;
   int dbg;  // TFX_DEBUG ablation bits (timing experiments only; results are wrong when set)
+  // fused agent step (Repeater + Remi, traffic_test.py:27-64): `passed` (and, without Remi, the
+  // rewards) accumulate over the ticks of the step; an env that overflowed in an earlier tick of
+  // the step stands still for the rest of it (`if done: break`, traffic_test.py:55)
+  int agent_mode, accum_rewards;
+  const int *agent_first;  // tick at which the current agent step began
   float length, rate, car_v, car_l, car_a, car_v0, car_b, car_T, car_s0;
   float two_sab, eps, thresh, near_end, ovf_pen;
   float r_two_sab, r_v0;  // correctly rounded reciprocals of the two constant divisors
@@ -121,6 +126,14 @@ __device__ __forceinline__ void idm_step_fast(const Dev &d, float x, float v, fl
   const float dx = d.rate * v + (0.5f * dvr) * d.rate;
   xn = x + (dx > 0.0f ? dx : 0.0f * dx);
   vn = np_max0(v + dvr);
+}
+
+// env stopped for the rest of the current agent step: it overflowed in one of the step's earlier
+// ticks (done_tick holds overflow tick + 1)
+__device__ __forceinline__ bool env_frozen(const Dev &d, int env, int tick) {
+  if (!d.agent_mode) return false;
+  const int dt = d.done_tick[env];
+  return dt > *d.agent_first && dt <= tick;
 }
 
 // TrafficEnv._step lines :225-232 for one intersection: new phase and elapsed from the old ones.

@@ -67,6 +67,13 @@ struct tfx_handle_s {
   int move_variant = 0;
   size_t move_lds = 0;
   unsigned long long div_mismatches = 0;  // result of the reciprocal-division self-test
+  // fused agent step: the launch sequence of one step, captured once per (ticks, remi, inputs)
+  hipGraph_t ag_graph = nullptr;
+  hipGraphExec_t ag_exec = nullptr;
+  hipStream_t ag_stream = nullptr;
+  std::string ag_key;
+  bool use_graph = true;  // TFX_GRAPH=0 disables
+  bool size_only = false;
 };
 
 namespace {
@@ -140,6 +147,7 @@ int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
       HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->move_lds));
     h->grid_move = move_grid(h, kern, 256, h->move_lds);
   }
+  if (h->size_only) return TFX_OK;
   hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), h->move_lds, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -148,6 +156,7 @@ int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
 template <int WPR>
 int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
   if (h->grid_move == 0) h->grid_move = move_grid(h, k_move<WPR>, 256 / (64 * WPR));
+  if (h->size_only) return TFX_OK;
   hipLaunchKernelGGL(k_move<WPR>, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -182,6 +191,15 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   }
 }
 
+// sizes the move kernel's grid without launching (the occupancy queries must not run inside a
+// stream capture)
+int launch_move_probe(tfx_handle h) {
+  h->size_only = true;
+  const int rc = launch_move(h, 0, nullptr);
+  h->size_only = false;
+  return rc;
+}
+
 int grid_for(long items, int n_cu) {
   long g = (items + 255) / 256;
   const long cap = (long)n_cu * 8;
@@ -199,6 +217,81 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace {
+
+// the launches of one agent step, in order, on `st`
+int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
+                   hipStream_t st) {
+  Dev &d = h->d;
+  hipLaunchKernelGGL(k_agent_begin, dim3(1), dim3(1), 0, st, d, const_cast<int *>(d.agent_first));
+  HIPCHK(hipGetLastError());
+  const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
+  d.agent_mode = 1;
+  d.accum_rewards = remi ? 0 : 1;
+  int rc = TFX_OK;
+  for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
+    rc = launch_move(h, t, st);
+    if (rc == TFX_OK) rc = launch_advance(h, t, st);
+  }
+  d.agent_mode = keep_mode;
+  d.accum_rewards = keep_acc;
+  if (rc != TFX_OK) return rc;
+  if (remi) {
+    hipLaunchKernelGGL(k_remi, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d);
+    HIPCHK(hipGetLastError());
+  }
+  if (aobs) {
+    hipLaunchKernelGGL(k_agent_obs, dim3(grid_for((long)d.E * (2 * d.r + d.I), h->n_cu)), dim3(256), 0, st, d, aobs);
+    HIPCHK(hipGetLastError());
+  }
+  if (areward)
+    HIPCHK(hipMemcpyAsync(areward, d.rewards, (size_t)d.E * d.I * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (adone) {
+    hipLaunchKernelGGL(k_done_since, dim3(grid_for(d.E, h->n_cu)), dim3(256), 0, st, d, adone, d.agent_first);
+    HIPCHK(hipGetLastError());
+  }
+  return TFX_OK;
+}
+
+}  // namespace
+
+extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
+                              uint8_t *adone, void *stream) {
+  if (int rc = check_handle(h, true)) return rc;
+  if (n_ticks < 1) return fail(TFX_EINVAL, "n_ticks < 1");
+  if (h->action_per_tick || h->spawn_per_tick)
+    return fail(TFX_EINVAL, "the fused agent step holds one action for all its ticks and needs a spawn rule "
+                            "that does not advance on the host (none, periodic, or one fixed count buffer)");
+  hipStream_t st = (hipStream_t)stream;
+  const Dev &d = h->d;
+  if (!h->use_graph) return agent_sequence(h, n_ticks, remi, aobs, areward, adone, st);
+  // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
+  char key[512];
+  snprintf(key, sizeof key, "%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", n_ticks, remi, (void *)aobs,
+           (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
+           (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
+           (void *)d.rewards, (void *)d.leading, (void *)d.lastcar, (void *)d.waiting, (void *)d.done_tick);
+  if (!h->ag_exec || h->ag_key != key) {
+    if (h->ag_exec) { (void)hipGraphExecDestroy(h->ag_exec); h->ag_exec = nullptr; }
+    if (h->ag_graph) { (void)hipGraphDestroy(h->ag_graph); h->ag_graph = nullptr; }
+    if (!h->ag_stream) HIPCHK(hipStreamCreateWithFlags(&h->ag_stream, hipStreamNonBlocking));
+    if (h->grid_move == 0) {  // size the move grid outside the capture (occupancy queries)
+      if (int rc = launch_move_probe(h)) return rc;
+    }
+    HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream);
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(h->ag_stream, &g);
+    if (rc != TFX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess) return fail(TFX_EDEVICE, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    h->ag_graph = g;
+    HIPCHK(hipGraphInstantiate(&h->ag_exec, g, nullptr, nullptr, 0));
+    h->ag_key = key;
+  }
+  HIPCHK(hipGraphLaunch(h->ag_exec, st));
+  return TFX_OK;
+}
 
 extern "C" {
 
@@ -223,6 +316,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   h->cfg = *cfg;
   build_tables(h);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
+  if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -301,6 +395,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.veh = (unsigned long long *)(base + o_misc);
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
+  d.agent_first = (const int *)(base + o_misc + 48);
   // reciprocal division is used only if it is exact for this handle's constants on the whole
   // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
   d.fastdiv = 0;
@@ -329,6 +424,9 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
 int tfx_destroy(tfx_handle h) {
   if (!h) return TFX_OK;
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->ag_exec) (void)hipGraphExecDestroy(h->ag_exec);
+  if (h->ag_graph) (void)hipGraphDestroy(h->ag_graph);
+  if (h->ag_stream) (void)hipStreamDestroy(h->ag_stream);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
   if (h->dev_scratch) (void)hipFree(h->dev_scratch);
   delete h;

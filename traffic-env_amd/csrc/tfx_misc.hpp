@@ -79,6 +79,37 @@ __global__ void k_done(const Dev d, uint8_t *out, int since_tick) {
     out[env] = d.done_tick[env] > since_tick ? 1 : 0;
 }
 
+// done flags of an agent step: overflow in any tick since the step began
+__global__ void k_done_since(const Dev d, uint8_t *out, const int *first) {
+  const int f = *first;
+  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < d.E; env += gridDim.x * blockDim.x)
+    out[env] = d.done_tick[env] > f ? 1 : 0;
+}
+
+// start of a fused agent step: remember the tick it starts at (env_frozen compares against it)
+__global__ void k_agent_begin(const Dev d, int *first) { *first = *d.tickA; }
+
+// Repeater's observation (traffic_test.py:48-53): [sum of passed | last detected | elapsed/100 *
+// (2*phase - 1)] as float32, from the int obs the ticks left behind (passed accumulated in place).
+__global__ void k_agent_obs(const Dev d, float *aobs) {
+  const int alen = 2 * d.r + d.I;
+  const long total = (long)d.E * alen;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+    const int env = (int)(g / alen);
+    const int k = (int)(g - (long)env * alen);
+    const int *ob = d.obs + (size_t)env * d.obs_len;
+    float v;
+    if (k < 2 * d.r) {
+      v = (float)ob[k];
+    } else {
+      const int i = k - 2 * d.r;
+      const int mult = 2 * ob[2 * d.r + i] - 1;
+      v = (float)((double)ob[2 * d.r + d.I + i] / 100.0 * (double)mult);
+    }
+    aobs[g] = v;
+  }
+}
+
 // Exhaustive check of div_const(a, c, rc) == a / c over every float a with lo <= |a| <= hi (both
 // signs) and a == +-0.  Signed zeros compare equal (the consumers add the quotient to another
 // value or raise it to the 4th power, so the sign of a zero quotient never survives).

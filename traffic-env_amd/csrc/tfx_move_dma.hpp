@@ -83,10 +83,13 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     const int id = valid ? (int)(base + lane) : (int)(total - 1);
     const int env = id / d.R;
     const int e = id - env * d.R;
-    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, valid, valid);
+    const bool frozen = valid && env_frozen(d, env, tick);
+    const bool run = valid && !frozen;
+    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
     const int pk = pack_desc(p.ld, p.lc, p.n_old, p.n_tot);
     // roads of this tile that received cars this tick (bit j = road j), wave-uniform
-    const unsigned long long spawn_mask = __builtin_amdgcn_ballot_w64(valid && p.n_tot != p.n_old);
+    const unsigned long long spawn_mask = __builtin_amdgcn_ballot_w64(run && p.n_tot != p.n_old);
+    const unsigned long long frozen_mask = __builtin_amdgcn_ballot_w64(frozen);
     const int xL_bits = __float_as_int(p.xL), xs0_bits = __float_as_int(p.xs0);
 
     // ================= phase C: sub-tiles of S roads through LDS =================================
@@ -252,13 +255,15 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
       };
 
       const unsigned long long sub_spawn = (spawn_mask >> j0) & ((1ull << S) - 1ull);
-      if (ns == S && sub_spawn == 0ull) {
+      const unsigned long long sub_frozen = (frozen_mask >> j0) & ((1ull << S) - 1ull);
+      if (ns == S && (sub_spawn | sub_frozen) == 0ull) {
         for (int jj0 = 0; jj0 < S; jj0 += UNR) {
 #pragma unroll
           for (int ju = 0; ju < UNR; ++ju) road(jj0 + ju, std::false_type{});
         }
       } else {
         for (int jj = 0; jj < ns; ++jj) {
+          if ((sub_frozen >> jj) & 1ull) continue;  // the road's image goes back unchanged
           if ((sub_spawn >> jj) & 1ull) road(jj, std::true_type{});
           else road(jj, std::false_type{});
         }
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     }
 
     // ================= phase W: lane j finishes road j ==========================================
-    if (valid) {
+    if (run) {
       const unsigned long long live = lane_mask_below(p.n_tot);
       const unsigned long long m_pop = ((unsigned long long)(unsigned)mp1 << 32 | (unsigned)mp0) & live;
       const unsigned long long m_wait = ((unsigned long long)(unsigned)mw1 << 32 | (unsigned)mw0) & live;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
           d.waiting[(size_t)env * d.r + e] += __popcll(m_wait);
           ob[d.r + e] = __popcll(m_det);
         }
-        ob[e] = kpop;
+        ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, r_t, p.n_tot);

@@ -43,9 +43,10 @@ __global__ __launch_bounds__(256) void k_move(const Dev d, const int tidx) {
 
   for (long grp = g0; grp < g1; ++grp) {
     const long idl = grp * RPB + lr;
-    const bool active = idl < total;
-    const int id = __builtin_amdgcn_readfirstlane((int)(active ? idl : 0));
+    const bool in_range = idl < total;
+    const int id = __builtin_amdgcn_readfirstlane((int)(in_range ? idl : 0));
     const int env = id / d.R;
+    const bool active = in_range && !env_frozen(d, env, tick);  // a frozen env's roads stand still
     const int e = id - env * d.R;
     const bool train = e < d.r;
     const int dst = train ? e % d.I : 0;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void k_move(const Dev d, const int tidx) {
             d.waiting[(size_t)env * d.r + e] += n_wait;
             ob[d.r + e] = n_det;
           }
-          ob[e] = kpop;
+          ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
           if (kpop > 0) d.passed_dst[(size_t)env * d.I + dst] = 1;
         }
         int *rp = reinterpret_cast<int *>(d.rec + id);

@@ -51,6 +51,7 @@ _PROTOS = {
     "tfx_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "tfx_move_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_advance_finished_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tfx_agent_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tfx_remi": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_cars_on_roads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tfx_done": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -94,6 +94,10 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_bind_buffers(h, C.byref(b)))
         self._action_buf = None
         self._spawn_buf = None
+        self._held_action = None
+        self._held_spawn = None
+        self._action_bound = None
+        self._spawn_bound = False
         self.tick = 0
         # views with the reference's attribute names (traffic_env.py:372-376)
         self.passed = self.obs[:, :r]
@@ -130,27 +134,51 @@ class TfxEngine(object):
 
     def set_actions(self, actions=None, cycle_period=None, per_tick=False):
         """actions: int tensor/array [E,I] (or [I] broadcast; with per_tick a leading n_ticks
-        dim), or cycle_period for the on-device fixed cycle."""
+        dim), or cycle_period for the on-device fixed cycle.  Held (non per-tick) actions are copied
+        into a buffer the engine keeps, so the device pointer - and any captured graph - stays valid."""
         if cycle_period is not None:
             nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_CYCLE, None, int(cycle_period), 0))
+            self._action_bound = None
             return
         a = self._to_dev_i32(actions)
-        base = a.dim() - (1 if per_tick else 0)
-        mode = nat.ACTION_BROADCAST if base == 1 else nat.ACTION_BUFFER
-        self._action_buf = a
-        nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, int(bool(per_tick))))
+        if per_tick:
+            mode = nat.ACTION_BROADCAST if a.dim() == 2 else nat.ACTION_BUFFER
+            self._action_buf = a
+            self._action_bound = None
+            nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, 1))
+            return
+        mode = nat.ACTION_BROADCAST if a.dim() == 1 else nat.ACTION_BUFFER
+        if self._held_action is None or self._held_action.shape != a.shape:
+            self._held_action = torch.empty_like(a)
+            self._action_bound = None
+        self._held_action.copy_(a)
+        if self._action_bound != mode:
+            nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(self._held_action), 0, 0))
+            self._action_bound = mode
 
     def set_spawns(self, counts=None, period=None, per_tick=False):
         """counts: int [E,n_entry] (with per_tick: [n_ticks,E,n_entry]); period: on-device
         one-car-every-`period`-ticks per entry road; neither: no spawns."""
         if period is not None:
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_PERIODIC, None, int(period), 0))
+            self._spawn_bound = False
         elif counts is not None:
             c = self._to_dev_i32(counts)
-            self._spawn_buf = c
-            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, int(bool(per_tick))))
+            if per_tick:
+                self._spawn_buf = c
+                self._spawn_bound = False
+                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1))
+                return
+            if self._held_spawn is None or self._held_spawn.shape != c.shape:
+                self._held_spawn = torch.empty_like(c)
+                self._spawn_bound = False
+            self._held_spawn.copy_(c)
+            if not self._spawn_bound:
+                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(self._held_spawn), 0, 0))
+                self._spawn_bound = True
         else:
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_NONE, None, 0, 0))
+            self._spawn_bound = False
 
     def _to_dev_i32(self, a):
         if isinstance(a, torch.Tensor):
@@ -165,6 +193,20 @@ class TfxEngine(object):
             nat.check(self.lib.tfx_step(self.h, int(n_ticks), self._stream()))
             self.tick += int(n_ticks)
             nat.check(self.lib.tfx_done(self.h, _ptr(self.done), first, self._stream()))
+
+    def agent_step(self, n_ticks=10, remi=True):
+        """One agent decision fused on the device (Repeater + Remi of traffic_test.py:27-64) with the
+        inputs set by set_actions / set_spawns.  Returns (aobs f32 [E,2r+I], areward f32 [E,I],
+        adone u8 [E]) - buffers owned by the engine and overwritten by the next call."""
+        if getattr(self, "_aobs", None) is None:
+            self._aobs = torch.zeros((self.E, 2 * self.r + self.I), dtype=torch.float32, device=self.device)
+            self._arew = torch.zeros((self.E, self.I), dtype=torch.float32, device=self.device)
+            self._adone = torch.zeros((self.E,), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_agent_step(self.h, int(n_ticks), int(bool(remi)), _ptr(self._aobs),
+                                              _ptr(self._arew), _ptr(self._adone), self._stream()))
+        self.tick += int(n_ticks)
+        return self._aobs, self._arew, self._adone
 
     def move_cars(self):
         with torch.cuda.device(self.device):

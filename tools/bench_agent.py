@@ -1,0 +1,23 @@
+"""Agent-step throughput on the small configurations (launch-bound regime): fused HIP-graph agent
+step vs the same sequence launched eagerly vs plain tfx_step(10)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "traffic-env_amd")]
+import torch
+from gym_traffic import workload as wl
+
+def run(cfg, envs, mode, steps=200):
+    os.environ["TFX_GRAPH"] = "0" if mode == "eager" else "1"
+    eng = wl.setup_engine(cfg, envs=envs)
+    f = (lambda: eng.step(10)) if mode == "ticks" else (lambda: eng.agent_step(10, remi=True))
+    for _ in range(20): f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps): f()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dt / steps * 1e6
+
+for cfg, envs in (("cfg0", 1), ("cfg1", 16), ("cfg1", 1024), ("cfg2", 64)):
+    r = {m: run(cfg, envs, m) for m in ("graph", "eager", "ticks")}
+    print("%s envs=%d: agent step (10 ticks) graph %.0f us | eager %.0f us | tfx_step(10) %.0f us" % (cfg, envs, r["graph"], r["eager"], r["ticks"]))

@@ -60,8 +60,10 @@ enum {
 enum {
   TFX_ACTION_BUFFER = 0,    /* int32 [n_ticks or 1][E][I] device buffer */
   TFX_ACTION_BROADCAST = 1, /* int32 [n_ticks or 1][I]: same action for every env */
-  TFX_ACTION_CYCLE = 2      /* on-device fixed cycle: a = ((tick + env % period) / period) & 1
+  TFX_ACTION_CYCLE = 2,     /* on-device fixed cycle: a = ((tick + env % period) / period) & 1
                                (algorithms/fixed.py:6-7 with spacing = period, env-staggered) */
+  TFX_ACTION_GREEDY = 3     /* on-device greedy controller (algorithms/greedy.py:14-16): every `period`
+                               ticks phase 1 iff N-S approaches hold more cars than E-W ones */
 };
 
 /* how cars enter (TrafficEnv.add_new_cars, traffic_env.py:274-283) */
@@ -134,6 +136,12 @@ int tfx_refresh(tfx_handle h, void *stream);
 
 int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick);
 int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick);
+/* On-device form of the reference's Poisson generator (traffic_env.py:160-164): per env, gaps of
+ * round(Exp(1/cars_per_tick)) ticks between cars, each car on a uniformly drawn entry road; Philox
+ * streams keyed by (seed, global env id).  `cdf` (host pointer, n_cdf entries) holds
+ * P(gap <= k) * 2^32 for k = 0.. (the last entry must be 0xFFFFFFFF); gym_traffic/devrng.py builds it
+ * and mirrors the stream on the host. */
+int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uint32_t *cdf, int32_t n_cdf);
 
 /* TrafficEnv._step (traffic_env.py:224-248), n_ticks times: phase/elapsed update, spawns,
  * move_cars, advance_finished_cars | advance_hack, steps += 1. */

@@ -1,0 +1,88 @@
+"""On-device Poisson arrivals + greedy controller (cfg4's closed loop): the device
+stream is mirrored on the host (gym_traffic/devrng.py) and fed to the oracle together with the
+greedy rule evaluated on the oracle's own cars_on_roads - bit-equal trajectories, and independent
+of how the envs are sharded."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleEnv, live_mask
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from gym_traffic.core import TfxEngine  # noqa: E402
+from gym_traffic.devrng import PoissonMirror, gap_table, philox4x32  # noqa: E402
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vectors for philox4x32-10
+    assert philox4x32(0, 0, 0, 0, 0, 0) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert philox4x32(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == \
+        (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+
+
+def test_gap_table_is_the_round_exp_distribution():
+    cdf = gap_table(0.8).astype(np.float64) / 2 ** 32
+    rng = np.random.RandomState(0)
+    gaps = np.array([round(x) for x in rng.exponential(1 / 0.8, size=200000)])
+    for k in range(5):
+        assert abs((gaps <= k).mean() - cdf[k]) < 4e-3
+
+
+@pytest.mark.parametrize("cap,cpt,spacing", [(20, 1.4, 3), (130, 6.0, 2)])
+def test_device_poisson_and_greedy_vs_oracle(cap, cpt, spacing):
+    E, m, n, L, T, off = 5, 4, 3, 200.0, 90, 11
+    eng = TfxEngine(m, n, L, cap, n_envs=E, planes=2, env_id_offset=off)
+    orc = OracleEnv(m, n, L, cap, eng.dest, eng.phases, eng.nexts, n_envs=E)
+    ph = np.zeros((E, eng.I), np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    eng.set_poisson(cpt, seed=0x1234ABCD5678)
+    eng.set_greedy(spacing)
+    mirror = PoissonMirror(cpt, 0x1234ABCD5678, eng.n_entry, range(off, off + E))
+    act = np.zeros((E, eng.I), np.int32)
+    total = 0
+    for t in range(T):
+        if t % spacing == 0:
+            c = orc.cars_on_roads()                       # [E, m, n, 4]
+            act = (c.reshape(E, eng.I, 4).dot([1, 1, -1, -1]) < 0).astype(np.int32)
+        cnt = mirror.next_tick()
+        roads = [[int(eng.entrypoints[j]) for j in range(eng.n_entry) for _ in range(cnt[k, j])] for k in range(E)]
+        total += int(cnt.sum())
+        eng.step(1)
+        _, _, od = orc.step(act, roads)
+        assert np.array_equal(eng.done.cpu().numpy(), od), t
+        assert np.array_equal(eng.current_phase.cpu().numpy(), orc.current_phase), t
+        assert np.array_equal(eng.leading.cpu().numpy(), orc.leading), t
+        assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), t
+    assert total > 0.5 * cpt * T * E
+    x, v, _ = eng.planes_numpy()
+    ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+    for k in range(E):
+        live = live_mask(ld[k], lc[k], cap)
+        assert np.array_equal(x[k][live].view(np.int32), orc.x[k][live].view(np.int32))
+        assert np.array_equal(v[k][live].view(np.int32), orc.v[k][live].view(np.int32))
+    assert np.array_equal(eng.obs.cpu().numpy(), orc.obs)
+    # sharding independence: global env `off + 2` alone gives the same trajectory
+    solo = TfxEngine(m, n, L, cap, n_envs=1, planes=2, env_id_offset=off + 2)
+    solo.reset(ph[:1])
+    solo.set_poisson(cpt, seed=0x1234ABCD5678)
+    solo.set_greedy(spacing)
+    solo.step(T)
+    assert torch.equal(solo.leading[0], eng.leading[2]) and torch.equal(solo.obs[0], eng.obs[2])
+
+
+def test_device_inputs_inside_the_agent_graph():
+    """Poisson + greedy producers are part of the captured agent-step graph."""
+    eng = TfxEngine(3, 3, 150.0, 34, n_envs=8, planes=2)
+    ref = TfxEngine(3, 3, 150.0, 34, n_envs=8, planes=2)
+    for e in (eng, ref):
+        e.reset(np.zeros((8, e.I), np.int32))
+        e.set_poisson(2.0, seed=7)
+        e.set_greedy(3)
+    for _ in range(5):
+        eng.agent_step(9, remi=True)
+    ref.step(45)                      # no env overflows at this load, so nothing freezes
+    assert int(eng.done_tick.max()) == 0
+    assert torch.equal(eng.leading, ref.leading) and torch.equal(eng.lastcar, ref.lastcar)
+    assert int(eng.cars_on_roads_flat().sum()) > 100

@@ -167,3 +167,22 @@ def test_render_geometry():
     seg = car_segments(gr, state, leading, lastcar, 4.0)
     assert seg.shape == (2, 4)
     assert np.allclose(seg[0, 0] - seg[0, 2], 4.0) and np.allclose(seg[:, 1], seg[:, 3])
+
+
+def test_philox_known_answer_and_gap_table():
+    """Host mirror of the device arrival generator: Random123 known answers for philox4x32-10 and
+    the gap table against sampled round(Exp(mean))."""
+    from gym_traffic.devrng import philox4x32, gap_table, PoissonMirror
+    assert philox4x32(0, 0, 0, 0, 0, 0) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert philox4x32(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF) == \
+        (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    cdf = gap_table(0.8)
+    assert cdf[-1] == 0xFFFFFFFF and (np.diff(cdf.astype(np.int64)) >= 0).all()
+    p = cdf.astype(np.float64) / 2 ** 32
+    gaps = np.array([round(x) for x in np.random.RandomState(0).exponential(1 / 0.8, size=200000)])
+    for k in range(5):
+        assert abs((gaps <= k).mean() - p[k]) < 4e-3
+    # mean arrival rate of the mirrored stream ~ cars_per_tick; streams differ per env id
+    m = PoissonMirror(2.5, 99, 8, [0, 1])
+    tot = sum(m.next_tick() for _ in range(400))
+    assert abs(tot[0].sum() / 400.0 - 2.5) < 0.4 and not np.array_equal(tot[0], tot[1])

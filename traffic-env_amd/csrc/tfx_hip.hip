@@ -74,6 +74,12 @@ struct tfx_handle_s {
   std::string ag_key;
   bool use_graph = true;  // TFX_GRAPH=0 disables
   bool size_only = false;
+  // on-device Poisson arrivals / greedy controller (own buffers)
+  bool poisson = false, greedy = false;
+  int greedy_spacing = 3;
+  PoissonDev ps{};
+  void *dev_ps = nullptr;      // counts | gap_left | draws | cdf
+  int *dev_greedy = nullptr;   // [E][I] actions
 };
 
 namespace {
@@ -212,6 +218,20 @@ int grid_for(long items, int n_cu) {
   return (int)g;
 }
 
+// per-tick producers of the spawn counts / actions when they are generated on the device
+int launch_inputs(tfx_handle h, hipStream_t st) {
+  if (h->poisson) {
+    hipLaunchKernelGGL(k_poisson, dim3(grid_for(h->d.E, h->n_cu)), dim3(256), 0, st, h->d, h->ps);
+    HIPCHK(hipGetLastError());
+  }
+  if (h->greedy) {
+    hipLaunchKernelGGL(k_greedy, dim3(grid_for((long)h->d.E * h->d.I, h->n_cu)), dim3(256), 0, st, h->d,
+                       h->dev_greedy, h->greedy_spacing);
+    HIPCHK(hipGetLastError());
+  }
+  return TFX_OK;
+}
+
 int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   const Dev &d = h->d;
   const long items = (long)d.E * (d.I + d.R - d.r);
@@ -235,7 +255,8 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
   for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
-    rc = launch_move(h, t, st);
+    rc = launch_inputs(h, st);
+    if (rc == TFX_OK) rc = launch_move(h, t, st);
     if (rc == TFX_OK) rc = launch_advance(h, t, st);
   }
   d.agent_mode = keep_mode;
@@ -272,7 +293,8 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   if (!h->use_graph) return agent_sequence(h, n_ticks, remi, aobs, areward, adone, st);
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[512];
-  snprintf(key, sizeof key, "%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", n_ticks, remi, (void *)aobs,
+  snprintf(key, sizeof key, "%d%d%d|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", (int)h->poisson,
+           (int)h->greedy, h->greedy_spacing, n_ticks, remi, (void *)aobs,
            (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
            (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
            (void *)d.rewards, (void *)d.leading, (void *)d.lastcar, (void *)d.waiting, (void *)d.done_tick);
@@ -431,6 +453,8 @@ int tfx_destroy(tfx_handle h) {
   if (h->ag_exec) (void)hipGraphExecDestroy(h->ag_exec);
   if (h->ag_graph) (void)hipGraphDestroy(h->ag_graph);
   if (h->ag_stream) (void)hipStreamDestroy(h->ag_stream);
+  if (h->dev_ps) (void)hipFree(h->dev_ps);
+  if (h->dev_greedy) (void)hipFree(h->dev_greedy);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
   if (h->dev_scratch) (void)hipFree(h->dev_scratch);
   delete h;
@@ -498,6 +522,21 @@ int tfx_refresh(tfx_handle h, void *stream) {
 int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick) {
   if (int rc = check_handle(h, false)) return rc;
   Dev &d = h->d;
+  h->greedy = false;
+  if (mode == TFX_ACTION_GREEDY) {
+    if (period < 1) return fail(TFX_EINVAL, "greedy spacing must be >= 1");
+    if (!h->dev_greedy) {
+      HIPCHK(hipMalloc((void **)&h->dev_greedy, (size_t)d.E * d.I * sizeof(int)));
+      HIPCHK(hipMemset(h->dev_greedy, 0, (size_t)d.E * d.I * sizeof(int)));
+    }
+    h->greedy = true;
+    h->greedy_spacing = period;
+    d.action = h->dev_greedy;
+    d.action_stride = 0;
+    d.action_mode = TFX_ACTION_BUFFER;
+    h->action_per_tick = 0;
+    return TFX_OK;
+  }
   if (mode == TFX_ACTION_CYCLE) {
     if (period < 1) return fail(TFX_EINVAL, "cycle period must be >= 1");
     d.action_period = period;
@@ -516,6 +555,7 @@ int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t peri
 int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick) {
   if (int rc = check_handle(h, false)) return rc;
   Dev &d = h->d;
+  h->poisson = false;
   if (mode == TFX_SPAWN_PERIODIC) {
     if (period < 1) return fail(TFX_EINVAL, "spawn period must be >= 1");
     d.spawn_period = period;
@@ -531,6 +571,35 @@ int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t perio
   return TFX_OK;
 }
 
+int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uint32_t *cdf, int32_t n_cdf) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (!(cars_per_tick > 0.0)) return fail(TFX_EINVAL, "cars_per_tick must be > 0");
+  if (!cdf || n_cdf < 1 || n_cdf > 65536) return fail(TFX_EINVAL, "gap table missing or too long");
+  Dev &d = h->d;
+  if (d.n_entry < 1) return fail(TFX_EINVAL, "no entry roads");
+  if (h->dev_ps) { (void)hipFree(h->dev_ps); h->dev_ps = nullptr; }
+  const size_t n_counts = (size_t)d.E * d.n_entry;
+  const size_t bytes = (n_counts + 2 * (size_t)d.E + (size_t)n_cdf) * 4;
+  HIPCHK(hipMalloc(&h->dev_ps, bytes));
+  HIPCHK(hipMemset(h->dev_ps, 0, bytes));
+  int *base = (int *)h->dev_ps;
+  h->ps.counts = base;
+  h->ps.gap_left = base + n_counts;
+  h->ps.draws = (unsigned *)(base + n_counts + d.E);
+  h->ps.cdf = (const unsigned *)(base + n_counts + 2 * (size_t)d.E);
+  h->ps.n_cdf = n_cdf;
+  h->ps.seed_lo = (unsigned)seed;
+  h->ps.seed_hi = (unsigned)(seed >> 32);
+  HIPCHK(hipMemset(h->ps.gap_left, 0xff, (size_t)d.E * 4));  // -1: first gap not drawn yet
+  HIPCHK(hipMemcpy((void *)h->ps.cdf, cdf, (size_t)n_cdf * 4, hipMemcpyHostToDevice));
+  d.spawn = h->ps.counts;
+  d.spawn_stride = 0;
+  d.spawn_mode = TFX_SPAWN_COUNTS;
+  h->spawn_per_tick = 0;
+  h->poisson = true;
+  return TFX_OK;
+}
+
 int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (n_ticks < 0) return fail(TFX_EINVAL, "n_ticks < 0");
@@ -538,6 +607,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   for (int t = 0; t < n_ticks; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (int rc = launch_inputs(h, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[0], st));
     if (int rc = launch_move(h, t, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[1], st));
@@ -552,6 +622,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
 
 int tfx_move_cars(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
+  if (int rc = launch_inputs(h, (hipStream_t)stream)) return rc;
   return launch_move(h, 0, (hipStream_t)stream);
 }
 

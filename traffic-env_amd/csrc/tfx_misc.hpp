@@ -79,6 +79,92 @@ __global__ void k_done(const Dev d, uint8_t *out, int since_tick) {
     out[env] = d.done_tick[env] > since_tick ? 1 : 0;
 }
 
+// ---- on-device arrivals and controller ---------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so env k's stream depends only on
+// (seed, global env id, draw index) - identical however the envs are sharded over GPUs.
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                           unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// The reference's Poisson generator (traffic_env.py:160-164) with a device RNG: one arrival
+// process per env; gaps between cars are round(Exp(mean)) whole ticks - drawn here by inverting the
+// gap's exact distribution through a host-built table of 32-bit thresholds (cdf[k] = P(gap <= k)
+// scaled to 2^32), so host mirror and device agree to the bit without transcendental functions;
+// every car picks an entry road uniformly (rand.choice(entrypoints), :280).  One lane per env;
+// writes this tick's car count per entry road.
+struct PoissonDev {
+  int *counts;             // [E][n_entry]
+  int *gap_left;           // [E] whole ticks until the next car; -1 = not drawn yet
+  unsigned *draws;         // [E] Philox draw counter
+  const unsigned *cdf;     // [n_cdf] thresholds
+  int n_cdf;
+  unsigned seed_lo, seed_hi;
+};
+
+__global__ void k_poisson(const Dev d, const PoissonDev ps) {
+  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < d.E; env += gridDim.x * blockDim.x) {
+    int *row = ps.counts + (size_t)env * d.n_entry;
+    for (int j = 0; j < d.n_entry; ++j) row[j] = 0;
+    if (env_frozen(d, env, *d.tickA)) continue;
+    int gap = ps.gap_left[env];
+    unsigned n = ps.draws[env];
+    const unsigned gid = (unsigned)(env + d.env_off);
+    unsigned u[4];
+    auto draw_gap = [&]() {
+      philox4x32(n++, gid, 0x47415021u, 0u, ps.seed_lo, ps.seed_hi, u);
+      int k = 0;
+      while (k < ps.n_cdf - 1 && u[0] >= ps.cdf[k]) ++k;  // cdf[n_cdf-1] catches the tail
+      return k;
+    };
+    if (gap < 0) gap = draw_gap();
+    for (int guard = 0; guard < 4096; ++guard) {
+      if (gap > 0) {
+        --gap;
+        break;
+      }
+      philox4x32(n++, gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
+      row[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)] += 1;
+      gap = draw_gap();
+    }
+    ps.gap_left[env] = gap;
+    ps.draws[env] = n;
+  }
+}
+
+// The greedy controller (algorithms/greedy.py:14-16): every `spacing` ticks, phase 1 iff the two
+// N-S approaches hold more cars than the two E-W ones (cars_on_roads().dot([1,1,-1,-1]) < 0);
+// between decisions the action is held.  One lane per intersection; runs before k_move so the
+// counts are the ones an agent would observe before stepping.
+__global__ void k_greedy(const Dev d, int *action, int spacing) {
+  const int tick = *d.tickA;
+  if (tick % spacing != 0) return;
+  const long total = (long)d.E * d.I;
+  for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+    const int env = (int)(g / d.I);
+    const int i = (int)(g - (long)env * d.I);
+    int c[4];
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) {
+      const int id = env * d.R + dir * d.I + i;
+      c[dir] = ring_count(d.leading[id], d.lastcar[id], d.C);
+    }
+    action[g] = (c[0] + c[1] - c[2] - c[3] < 0) ? 1 : 0;
+  }
+}
+
 // done flags of an agent step: overflow in any tick since the step began
 __global__ void k_done_since(const Dev d, uint8_t *out, const int *first) {
   const int f = *first;

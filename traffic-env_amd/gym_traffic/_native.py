@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libtfx_hip.so"))
 
-ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE = 0, 1, 2
+ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
 ABI_VERSION = 2
 
@@ -48,6 +48,7 @@ _PROTOS = {
     "tfx_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_set_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_spawns": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    "tfx_set_poisson": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int32]),
     "tfx_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "tfx_move_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_advance_finished_cars": (C.c_int, [C.c_void_p, C.c_void_p]),

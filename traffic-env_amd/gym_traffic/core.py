@@ -132,6 +132,20 @@ class TfxEngine(object):
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 
+    def set_poisson(self, cars_per_tick, seed=0):
+        """On-device Poisson arrivals (the reference's generator, traffic_env.py:160-164, with a
+        counter-based RNG): cars_per_tick = cars_per_sec * rate for the whole env."""
+        from gym_traffic.devrng import gap_table
+        cdf = gap_table(cars_per_tick)
+        nat.check(self.lib.tfx_set_poisson(self.h, float(cars_per_tick), int(seed),
+                                           cdf.ctypes.data_as(C.c_void_p), int(cdf.size)))
+        self._spawn_bound = False
+
+    def set_greedy(self, spacing=3):
+        """On-device greedy controller (algorithms/greedy.py:14-16), a decision every `spacing` ticks."""
+        nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_GREEDY, None, int(spacing), 0))
+        self._action_bound = None
+
     def set_actions(self, actions=None, cycle_period=None, per_tick=False):
         """actions: int tensor/array [E,I] (or [I] broadcast; with per_tick a leading n_ticks
         dim), or cycle_period for the on-device fixed cycle.  Held (non per-tick) actions are copied

@@ -1,0 +1,78 @@
+"""Host mirror of the on-device arrival generator (csrc/tfx_misc.hpp k_poisson).
+
+The device draws car arrivals with Philox4x32-10 streams keyed by (seed, global env id) and turns
+uniforms into whole-tick gaps through a table of 32-bit thresholds built here from the exact
+distribution of `round(Exp(mean))` - the reference's gap rule (traffic_env.py:161-163; Python's
+round is half-to-even: gap k >= 1 covers [k - 1/2, k + 1/2], with the ties at even k).  Because both
+sides compare the same integers, `PoissonMirror` reproduces the device's (tick, road) sequence bit
+for bit; tests feed it to the oracle.
+"""
+import math
+
+import numpy as np
+
+M0, M1 = 0xD2511F53, 0xCD9E8D57
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+TAG_GAP, TAG_ROAD = 0x47415021, 0x524F4144
+MASK = 0xFFFFFFFF
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & MASK, p1 & MASK, ((p0 >> 32) ^ c3 ^ k1) & MASK, p0 & MASK
+        k0 = (k0 + W0) & MASK
+        k1 = (k1 + W1) & MASK
+    return c0, c1, c2, c3
+
+
+def gap_table(cars_per_tick, tail=1e-12):
+    """uint32 thresholds cdf[k] = floor(P(gap <= k) * 2^32), last entry 0xFFFFFFFF."""
+    mean = 1.0 / float(cars_per_tick)
+    cdf = []
+    k = 0
+    while True:
+        p = 1.0 - math.exp(-(k + 0.5) / mean)            # P(Exp(mean) < k + 1/2)
+        cdf.append(min(MASK, int(p * 4294967296.0)))
+        if 1.0 - p < tail or k > 60000:
+            break
+        k += 1
+    cdf[-1] = MASK
+    return np.asarray(cdf, np.uint32)
+
+
+class PoissonMirror(object):
+    def __init__(self, cars_per_tick, seed, n_entry, env_ids):
+        self.cdf = [int(c) for c in gap_table(cars_per_tick)]
+        self.k0, self.k1 = int(seed) & MASK, (int(seed) >> 32) & MASK
+        self.n_entry = int(n_entry)
+        self.env_ids = [int(e) for e in env_ids]
+        self.gap = {e: -1 for e in self.env_ids}
+        self.draws = {e: 0 for e in self.env_ids}
+
+    def _gap(self, e):
+        u = philox4x32(self.draws[e], e, TAG_GAP, 0, self.k0, self.k1)[0]
+        self.draws[e] += 1
+        k = 0
+        while k < len(self.cdf) - 1 and u >= self.cdf[k]:
+            k += 1
+        return k
+
+    def next_tick(self, frozen=()):
+        """int32 [len(env_ids), n_entry] cars per entry road this tick (entry index order)."""
+        out = np.zeros((len(self.env_ids), self.n_entry), np.int32)
+        for row, e in enumerate(self.env_ids):
+            if e in frozen:
+                continue
+            if self.gap[e] < 0:
+                self.gap[e] = self._gap(e)
+            while True:
+                if self.gap[e] > 0:
+                    self.gap[e] -= 1
+                    break
+                u = philox4x32(self.draws[e], e, TAG_ROAD, 0, self.k0, self.k1)[0]
+                self.draws[e] += 1
+                out[row, (u * self.n_entry) >> 32] += 1
+                self.gap[e] = self._gap(e)
+        return out

@@ -123,11 +123,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, a.gpus))
+    # TFX_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo - a one-GPU dry run of the N > 1 path
+    rehearsal = os.environ.get("TFX_BENCH_REHEARSAL") == "1"
+    local = 0 if rehearsal else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     c = wl.CONFIGS[a.config]
     E = int(a.envs if a.envs is not None else c["envs"])
@@ -165,8 +171,9 @@ def main():
     updates = eng.vehicle_updates()
     prof = eng.profile_read()
     eng.profile(0)
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    uu = torch.tensor([updates], dtype=torch.float64, device=device)
+    red_dev = torch.device("cpu") if rehearsal else device
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    uu = torch.tensor([updates], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)

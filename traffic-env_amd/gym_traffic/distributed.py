@@ -24,13 +24,17 @@ class RolloutGather(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = torch.device(device)
+        # gloo cannot gather device tensors: rehearsals on one GPU (and CPU tests) stage through host
+        # memory; with RCCL ("nccl") the snapshots stay on the device
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.stage_dev = torch.device("cpu") if (backend == "gloo" and self.device.type == "cuda") else self.device
         self.shapes = ((n_local, obs_len), (n_local, n_intersections), (n_local,))
         self.dtypes = (torch.int32, torch.float32, torch.uint8)
         # snapshots: obs/rewards are live buffers the next tick overwrites
-        self.snap = [torch.empty(s, dtype=t, device=self.device) for s, t in zip(self.shapes, self.dtypes)]
+        self.snap = [torch.empty(s, dtype=t, device=self.stage_dev) for s, t in zip(self.shapes, self.dtypes)]
         self.recv = None
         if self.rank == dst and self.world > 1:
-            self.recv = [[torch.empty(s, dtype=t, device=self.device) for _ in range(self.world)]
+            self.recv = [[torch.empty(s, dtype=t, device=self.stage_dev) for _ in range(self.world)]
                          for s, t in zip(self.shapes, self.dtypes)]
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.pending = []
@@ -46,6 +50,8 @@ class RolloutGather(object):
         with ctx:
             for s, t in zip(self.snap, (obs, rewards, done)):
                 s.copy_(t, non_blocking=True)
+            if self.stage_dev.type == "cpu" and self.side is not None:
+                self.side.synchronize()            # host copies must have landed before gloo reads them
             if self.world > 1:
                 for k, s in enumerate(self.snap):
                     self.pending.append(dist.gather(s, self.recv[k] if self.rank == self.dst else None,

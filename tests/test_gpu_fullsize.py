@@ -112,3 +112,32 @@ def test_cfg4_shape_two_waves_per_road_vs_oracle():
             assert np.array_equal(v[k][live].view(np.int32), orc.v[k][live].view(np.int32))
     finally:
         del wl.CONFIGS["_cfg4_small"]
+
+
+def test_cfg4_capacity_two_pass_tiled_kernel_vs_oracle():
+    """CAPACITY = 130 (cfg4's 128-car roads) at a batch large enough for the tiled LDS-DMA kernel:
+    a wavefront takes each road in two passes of 64 cars.  16x16 grid x 16 envs, heavy prefill so
+    both passes are busy, against the oracle bit for bit."""
+    c = dict(wl.CONFIGS["cfg4"], m=16, n=16, envs=16, prefill=100)
+    wl.CONFIGS["_cfg4_tiled"] = c
+    try:
+        eng = wl.setup_engine("_cfg4_tiled")
+        assert eng.E * eng.R >= 64 * 256
+        orc, ids = oracle_for(eng, c, 16, 0)
+        for t in range(36):
+            eng.step(1)
+            _, _, od = step_oracle(orc, ids, eng, t, threads=8)
+            assert np.array_equal(eng.done.cpu().numpy(), od), t
+        assert eng.launch_info()["waves_per_road"] == 2
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        assert np.array_equal(ld, orc.leading) and np.array_equal(lc, orc.lastcar)
+        assert np.array_equal(eng.obs.cpu().numpy(), orc.obs)
+        assert np.array_equal(eng.waiting.cpu().numpy(), orc.waiting)
+        x, v, _ = eng.planes_numpy()
+        for k in range(16):
+            live = live_mask(ld[k], lc[k], eng.C)
+            assert np.array_equal(x[k][live].view(np.int32), orc.x[k][live].view(np.int32)), k
+            assert np.array_equal(v[k][live].view(np.int32), orc.v[k][live].view(np.int32)), k
+        assert int((lc != ld).sum()) > 1000 and int(eng.cars_on_roads_flat().max()) > 64
+    finally:
+        del wl.CONFIGS["_cfg4_tiled"]

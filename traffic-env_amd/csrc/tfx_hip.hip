@@ -144,9 +144,9 @@ int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds 
 }
 
 // k_move_dma<CC, S, NBUF, UNR, LEADER_LDS>: size the grid on first use, then launch
-template <int CC, int S, int NBUF, int UNR, bool LDSL, int LIVE = 0>
+template <int CC, int S, int NBUF, int UNR, bool LDSL, int LIVE = 0, int NP = 1>
 int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
-  auto kern = k_move_dma<CC, S, NBUF, UNR, LDSL, LIVE>;
+  auto kern = k_move_dma<CC, S, NBUF, UNR, LDSL, LIVE, NP>;
   if (h->grid_move == 0) {
     h->move_lds = (size_t)4 * NBUF * S * h->d.C * sizeof(float2);
     if (h->move_lds > 64 * 1024)
@@ -170,10 +170,13 @@ int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
 
 // TFX_MOVE_VARIANT: 0 best known | 1 generic k_move<1> | 20.. tuning points of k_move_dma
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {
-  if (h->wpr == 2) return launch_generic<2>(h, tidx, st);
-  if (h->wpr == 4) return launch_generic<4>(h, tidx, st);
   const int C = h->d.C;
   const int v = h->move_variant;
+  // cfg4: 128-car roads take two passes of a wavefront through the tiled kernel
+  if (C == 130 && v != 1 && (long)h->d.E * h->d.R >= 64L * h->n_cu)
+    return launch_dma<130, 8, 2, 2, false, 2, 2>(h, tidx, st);
+  if (h->wpr == 2) return launch_generic<2>(h, tidx, st);
+  if (h->wpr == 4) return launch_generic<4>(h, tidx, st);
   if ((C & 1) || v == 1) return launch_generic<1>(h, tidx, st);  // odd capacity: records not 16-B multiples
   // fewer roads than one 64-road tile per CU: the tiled kernel would leave most CUs idle and walk
   // its tile serially; one wavefront per road finishes sooner (measured: cfg0 96 -> 69 us, cfg1 x 16
@@ -221,7 +224,8 @@ int grid_for(long items, int n_cu) {
 // per-tick producers of the spawn counts / actions when they are generated on the device
 int launch_inputs(tfx_handle h, hipStream_t st) {
   if (h->poisson) {
-    hipLaunchKernelGGL(k_poisson, dim3(grid_for(h->d.E, h->n_cu)), dim3(256), 0, st, h->d, h->ps);
+    const int pg = h->d.E < h->n_cu * 16 ? h->d.E : h->n_cu * 16;
+    hipLaunchKernelGGL(k_poisson, dim3(pg), dim3(64), (size_t)h->d.n_entry * sizeof(int), st, h->d, h->ps);
     HIPCHK(hipGetLastError());
   }
   if (h->greedy) {

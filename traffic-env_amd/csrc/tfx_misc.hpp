@@ -103,44 +103,68 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
 // process per env; gaps between cars are round(Exp(mean)) whole ticks - drawn here by inverting the
 // gap's exact distribution through a host-built table of 32-bit thresholds (cdf[k] = P(gap <= k)
 // scaled to 2^32), so host mirror and device agree to the bit without transcendental functions;
-// every car picks an entry road uniformly (rand.choice(entrypoints), :280).  One lane per env;
-// writes this tick's car count per entry road.
+// every car picks an entry road uniformly (rand.choice(entrypoints), :280).  Writes this tick's
+// car count per entry road.
 struct PoissonDev {
   int *counts;             // [E][n_entry]
   int *gap_left;           // [E] whole ticks until the next car; -1 = not drawn yet
-  unsigned *draws;         // [E] Philox draw counter
+  unsigned *draws;         // [E] index of the next car of the env's stream
   const unsigned *cdf;     // [n_cdf] thresholds
   int n_cdf;
   unsigned seed_lo, seed_hi;
 };
 
-__global__ void k_poisson(const Dev d, const PoissonDev ps) {
-  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < d.E; env += gridDim.x * blockDim.x) {
-    int *row = ps.counts + (size_t)env * d.n_entry;
-    for (int j = 0; j < d.n_entry; ++j) row[j] = 0;
-    if (env_frozen(d, env, *d.tickA)) continue;
-    int gap = ps.gap_left[env];
-    unsigned n = ps.draws[env];
-    const unsigned gid = (unsigned)(env + d.env_off);
-    unsigned u[4];
-    auto draw_gap = [&]() {
-      philox4x32(n++, gid, 0x47415021u, 0u, ps.seed_lo, ps.seed_hi, u);
-      int k = 0;
-      while (k < ps.n_cdf - 1 && u[0] >= ps.cdf[k]) ++k;  // cdf[n_cdf-1] catches the tail
-      return k;
-    };
-    if (gap < 0) gap = draw_gap();
-    for (int guard = 0; guard < 4096; ++guard) {
+// Draw indexing (fixed, so the stream is random-access): draw 0 = the first gap; car c (0-based)
+// uses draw 1 + 2c for its entry road and draw 2 + 2c for the gap that follows it.  One wavefront
+// per env evaluates 64 consecutive cars at a time: all cars up to and including the first one with
+// a non-zero gap arrive in this tick (the reference's generator yields bursts at high rates:
+// thousands of cars per tick at cfg4's nominal 15 cars/tick because gaps are rounded to ticks).
+__global__ __launch_bounds__(64) void k_poisson(const Dev d, const PoissonDev ps) {
+  extern __shared__ int s_hist[];  // [n_entry]
+  const int lane = threadIdx.x;
+  for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
+    for (int j = lane; j < d.n_entry; j += 64) s_hist[j] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (!env_frozen(d, env, *d.tickA)) {
+      int gap = ps.gap_left[env];
+      unsigned c0 = ps.draws[env];  // index of the next car
+      const unsigned gid = (unsigned)(env + d.env_off);
+      unsigned u[4];
+      auto gap_of = [&](unsigned draw) {
+        philox4x32(draw, gid, 0x47415021u, 0u, ps.seed_lo, ps.seed_hi, u);
+        int k = 0;
+        while (k < ps.n_cdf - 1 && u[0] >= ps.cdf[k]) ++k;  // cdf[n_cdf-1] catches the tail
+        return k;
+      };
+      if (gap < 0) gap = gap_of(0u);
       if (gap > 0) {
         --gap;
-        break;
+      } else {
+        for (int guard = 0; guard < 1024; ++guard) {  // <= 65536 cars per env-tick
+          const unsigned c = c0 + (unsigned)lane;
+          const int g = gap_of(2u + 2u * c);
+          const unsigned long long stop = __builtin_amdgcn_ballot_w64(g > 0);
+          const int f = stop ? __builtin_ctzll(stop) : 63;  // last car of this tick within the batch
+          if (lane <= f) {
+            philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
+            atomicAdd(&s_hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
+          }
+          c0 += (unsigned)(f + 1);
+          if (stop) {
+            gap = __shfl(g, f, 64) - 1;
+            break;
+          }
+        }
       }
-      philox4x32(n++, gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
-      row[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)] += 1;
-      gap = draw_gap();
+      if (lane == 0) {
+        ps.gap_left[env] = gap;
+        ps.draws[env] = c0;
+      }
     }
-    ps.gap_left[env] = gap;
-    ps.draws[env] = n;
+    __builtin_amdgcn_wave_barrier();
+    int *row = ps.counts + (size_t)env * d.n_entry;
+    for (int j = lane; j < d.n_entry; j += 64) row[j] = s_hist[j];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

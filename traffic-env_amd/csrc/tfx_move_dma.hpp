@@ -35,9 +35,9 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // toolchain; the LLVM intrinsic keeps it visible to the scheduler and the hazard recogniser)
 extern "C" __device__ int tfx_writelane_i32(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
-__device__ __forceinline__ int pack_desc(int ld, int lc, int n_old, int n_tot) {
-  return ld | (lc << 9) | (n_old << 18) | (n_tot << 25);
-}
+// per-road descriptor words handed from phase M to phase C: ring indices / car counts
+__device__ __forceinline__ int pack_idx(int ld, int lc) { return ld | (lc << 16); }
+__device__ __forceinline__ int pack_cnt(int n_old, int n_tot) { return n_old | (n_tot << 16); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -45,13 +45,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 __device__ __forceinline__ unsigned long long lane_mask_below(int n) {  // lanes 0 .. n-1
-  return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
 }
 
-template <int CC, int S, int NBUF, int UNR, bool LEADER_LDS, int LIVE>
+template <int CC, int S, int NBUF, int UNR, bool LEADER_LDS, int LIVE, int NP = 1>
 __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
   static_assert(NBUF == 1 || CC > 0, "multi-buffering needs a compile-time capacity");
   static_assert(NBUF >= 1 && NBUF <= 3, "1 to 3 LDS buffers");
+  static_assert(NP == 1 || (CC > 0 && !LEADER_LDS), "multi-pass roads: compile-time capacity, DPP leader");
+  static_assert(CC == 0 || CC - 2 <= 64 * NP, "NP passes of 64 lanes must cover the ring");
   static_assert(LIVE == 0 || CC > 0, "live-chunk streaming needs a compile-time capacity");
   constexpr int TR = 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
   const int sub_slots = S * C;  // (x, v) pairs per sub-tile
   float2 *bufs = reinterpret_cast<float2 *>(smem) + (size_t)wv * NBUF * sub_slots;
   constexpr int K_DMA = CC ? (S * CC * 8 + 1023) / 1024 : 0;  // DMA instructions per full sub-tile
-  const bool all_slots = (C - 1 >= 64);  // every lane's ring slot is a valid slot of the image
+  const bool all_slots = (C - 1 >= 64 * NP);  // every (pass, lane) ring position is a valid slot of the image
 
   // tiles are dealt round-robin over all waves of the grid: at any moment the waves in flight
   // cover one dense window of memory (DRAM rows are used while they are open)
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     const bool frozen = valid && env_frozen(d, env, tick);
     const bool run = valid && !frozen;
     const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
-    const int pk = pack_desc(p.ld, p.lc, p.n_old, p.n_tot);
+    const int pk = pack_idx(p.ld, p.lc), pn = pack_cnt(p.n_old, p.n_tot);
     // roads of this tile that received cars this tick (bit j = road j), wave-uniform
     const unsigned long long spawn_mask = __builtin_amdgcn_ballot_w64(run && p.n_tot != p.n_old);
     const unsigned long long frozen_mask = __builtin_amdgcn_ballot_w64(frozen);
@@ -97,7 +99,10 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
     const int nroads = left < TR ? (int)left : TR;
     float2 *tx = d.xv + (size_t)base * C;  // wave-uniform tile base, 16-byte aligned
     // road j's ballots, collected by lane j
-    int mw0 = 0, mw1 = 0, md0 = 0, md1 = 0, mp0 = 0, mp1 = 0, mf0 = 0, mf1 = 0, r_t = 0;
+    // (one set per pass of 64 cars for rings longer than a wavefront)
+    int mw0[NP], mw1[NP], md0[NP], md1[NP], mp0[NP], mp1[NP], mf0[NP], mf1[NP], r_t = 0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) mw0[pp] = mw1[pp] = md0[pp] = md1[pp] = mp0[pp] = mp1[pp] = mf0[pp] = mf1[pp] = 0;
 
     // LIVE > 0: only the 16-byte chunks (2 ring slots) that hold a live car are moved.  Bit i of
     // the returned mask says whether this lane's chunk of DMA instruction i is live; the same mask
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
           const int half = C >> 1;
           const int jj = q / half;
           const int s0 = 2 * (q - jj * half);                 // slots s0, s0 + 1
-          const int pkr = __shfl(pk, (j0 + jj) & 63, 64);
-          const int ldr = pkr & 511, nr = (int)((unsigned)pkr >> 25);
+          const int ldr = __shfl(pk, (j0 + jj) & 63, 64) & 0xffff;
+          const int nr = (int)((unsigned)__shfl(pn, (j0 + jj) & 63, 64) >> 16);
           int p0 = s0 - ldr - 1;                              // ring position of slot s0 behind the leader
           p0 += (p0 < 0) ? C - 1 : 0;
           int p1 = s0 - ldr;
@@ -183,75 +188,89 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
       auto road = [&](int jj, auto spawn_tag) {
         constexpr bool SPAWN = decltype(spawn_tag)::value;
         const int j = j0 + jj;
-        const int pkj = __builtin_amdgcn_readlane(pk, j);
+        const int pkj = __builtin_amdgcn_readlane(pk, j), pnj = __builtin_amdgcn_readlane(pn, j);
         const float xLj = __int_as_float(__builtin_amdgcn_readlane(xL_bits, j));
-        const int ldj = pkj & 511, lcj = (pkj >> 9) & 511, n_oldj = (pkj >> 18) & 127;
-        const int n_totj = (int)((unsigned)pkj >> 25);
+        const int ldj = pkj & 0xffff, lcj = (int)((unsigned)pkj >> 16);
+        const int n_oldj = pnj & 0xffff, n_totj = (int)((unsigned)pnj >> 16);
         float2 *rb = buf + jj * C;  // this road's record in LDS
-        // ring slot of car `lane`: positions run 0 .. C-2 from slot 1
-        const unsigned pos = (unsigned)(ldj + lane);  // (ld - 1) + (lane + 1)
-        const unsigned slot = 1u + min(pos, pos - (unsigned)(C - 1));
-        const bool in_img = all_slots || lane < C - 1;
-        const unsigned sl = in_img ? slot : 1u;
-        const float2 cv = rb[sl];
-        float x = cv.x, v = cv.y;
-        if (SPAWN) {  // cars spawned this tick are not in memory yet
-          if (lane >= n_oldj && lane < n_totj) {
-            x = spawned_x(d, __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j)), lane - n_oldj);
-            v = d.car_v;
-          }
-        }
-        float xl, vl;
-        if (LEADER_LDS && !SPAWN) {
-          // the car one ring slot ahead in the image; lane 0's leader is the fake one
-          const unsigned prev = (sl == 1u) ? (unsigned)(C - 1) : sl - 1u;
-          const float2 lv = rb[prev];
-          xl = (lane == 0) ? xLj : lv.x;
-          vl = (lane == 0) ? 0.0f : lv.y;
-        } else {
-          // wave_shr:1 - lane k receives lane k-1; lane 0 keeps `old` = the fake leader
-          xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(xLj), __float_as_int(x), 0x138, 0xf, 0xf, false));
-          vl = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
-        }
-
-        float xn, vn;
-        // the reciprocal form of the two constant-divisor divisions is exact on a verified domain;
-        // one live car outside it (denormal-range or non-finite speed) sends the road down the
-        // IEEE-divide path.  Wave-uniform branch.
-        const unsigned long long off_domain =
-            __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) & lane_mask_below(n_totj);
-        if (d.dbg & 2) {  // ablation: no IDM arithmetic
-          xn = x + (xl - ll);
-          vn = v + vl;
-        } else if (d.fastdiv && off_domain == 0ull) {
-          idm_step_fast(d, x, v, xl, vl, ll, xn, vn);
-        } else {
-          idm_step(d, x, v, xl, vl, ll, xn, vn);
-        }
-
-        // new state back into the image: lanes without a car rewrite dead slots with junk,
-        // which nothing reads (the 64 lanes cover every ring slot except `leading`)
-        if (in_img) rb[sl] = make_float2(xn, vn);
-        if (SPAWN && d.w) {
-          if (lane >= n_oldj && lane < n_totj) d.w[(size_t)base * C + j * C + slot] = (float)tick;
-        }
-        // wrapped ring: the reference tests x, not v, on the second segment (:210)
         const unsigned lc_seg2 = (ldj > lcj) ? (unsigned)lcj : 0u;
-        const float wq = (slot <= lc_seg2) ? xn : vn;
-        const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(wq < d.thresh);
-        const unsigned long long m_det = __builtin_amdgcn_ballot_w64(xn > d.near_end);
-        const unsigned long long m_pop = __builtin_amdgcn_ballot_w64(xn > d.length);
-        const unsigned long long m_far = __builtin_amdgcn_ballot_w64((xn - d.length) > d.length);
-        mw0 = tfx_writelane_i32((int)(unsigned)m_wait, j, mw0);
-        mw1 = tfx_writelane_i32((int)(unsigned)(m_wait >> 32), j, mw1);
-        md0 = tfx_writelane_i32((int)(unsigned)m_det, j, md0);
-        md1 = tfx_writelane_i32((int)(unsigned)(m_det >> 32), j, md1);
-        mp0 = tfx_writelane_i32((int)(unsigned)m_pop, j, mp0);
-        mp1 = tfx_writelane_i32((int)(unsigned)(m_pop >> 32), j, mp1);
-        mf0 = tfx_writelane_i32((int)(unsigned)m_far, j, mf0);
-        mf1 = tfx_writelane_i32((int)(unsigned)(m_far >> 32), j, mf1);
-        // x of the last car after the move (junk, and unused, when the road is empty)
-        r_t = tfx_writelane_i32(__builtin_amdgcn_readlane(__float_as_int(xn), n_totj > 0 ? n_totj - 1 : 0), j, r_t);
+        // leader of the first car of a pass: the fake leader, then the last car of the pass before
+        float lead_x = xLj, lead_v = 0.0f;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const int kk = pp * 64 + lane;  // car index behind the fake leader
+          if (NP > 1 && pp > 0 && pp * 64 >= n_totj) break;  // wave-uniform: no cars in this pass
+          // ring slot of car kk: positions run 0 .. C-2 from slot 1
+          const unsigned pos = (unsigned)(ldj + kk);  // (ld - 1) + (kk + 1)
+          const unsigned slot = 1u + min(pos, pos - (unsigned)(C - 1));
+          const bool in_img = all_slots || kk < C - 1;
+          const unsigned sl = in_img ? slot : 1u;
+          const float2 cv = rb[sl];
+          float x = cv.x, v = cv.y;
+          if (SPAWN) {  // cars spawned this tick are not in memory yet
+            if (kk >= n_oldj && kk < n_totj) {
+              x = spawned_x(d, __int_as_float(__builtin_amdgcn_readlane(xs0_bits, j)), kk - n_oldj);
+              v = d.car_v;
+            }
+          }
+          float xl, vl;
+          if (LEADER_LDS && !SPAWN) {
+            // the car one ring slot ahead in the image; lane 0's leader is the fake one
+            const unsigned prev = (sl == 1u) ? (unsigned)(C - 1) : sl - 1u;
+            const float2 lv = rb[prev];
+            xl = (lane == 0) ? xLj : lv.x;
+            vl = (lane == 0) ? 0.0f : lv.y;
+          } else {
+            // wave_shr:1 - lane k receives lane k-1; lane 0 keeps `old` = the leader of this pass
+            xl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lead_x), __float_as_int(x), 0x138, 0xf, 0xf, false));
+            vl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lead_v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+          }
+          if (NP > 1) {  // OLD state of this pass's last car leads the next pass (Jacobi)
+            lead_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+            lead_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+          }
+          const float llp = (pp == 0) ? ll : d.car_l;  // only the fake leader has length 0
+
+          float xn, vn;
+          // the reciprocal form of the two constant-divisor divisions is exact on a verified
+          // domain; one live car outside it (denormal-range or non-finite speed) sends the pass
+          // down the IEEE-divide path.  Wave-uniform branch.
+          const unsigned long long off_domain =
+              __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) & lane_mask_below(n_totj - pp * 64);
+          if (d.dbg & 2) {  // ablation: no IDM arithmetic
+            xn = x + (xl - llp);
+            vn = v + vl;
+          } else if (d.fastdiv && off_domain == 0ull) {
+            idm_step_fast(d, x, v, xl, vl, llp, xn, vn);
+          } else {
+            idm_step(d, x, v, xl, vl, llp, xn, vn);
+          }
+
+          // new state back into the image: lanes without a car rewrite dead slots with junk,
+          // which nothing reads (the lanes cover every ring slot except `leading`)
+          if (in_img) rb[sl] = make_float2(xn, vn);
+          if (SPAWN && d.w) {
+            if (kk >= n_oldj && kk < n_totj) d.w[(size_t)base * C + j * C + slot] = (float)tick;
+          }
+          // wrapped ring: the reference tests x, not v, on the second segment (:210)
+          const float wq = (slot <= lc_seg2) ? xn : vn;
+          const unsigned long long m_wait = __builtin_amdgcn_ballot_w64(wq < d.thresh);
+          const unsigned long long m_det = __builtin_amdgcn_ballot_w64(xn > d.near_end);
+          const unsigned long long m_pop = __builtin_amdgcn_ballot_w64(xn > d.length);
+          const unsigned long long m_far = __builtin_amdgcn_ballot_w64((xn - d.length) > d.length);
+          mw0[pp] = tfx_writelane_i32((int)(unsigned)m_wait, j, mw0[pp]);
+          mw1[pp] = tfx_writelane_i32((int)(unsigned)(m_wait >> 32), j, mw1[pp]);
+          md0[pp] = tfx_writelane_i32((int)(unsigned)m_det, j, md0[pp]);
+          md1[pp] = tfx_writelane_i32((int)(unsigned)(m_det >> 32), j, md1[pp]);
+          mp0[pp] = tfx_writelane_i32((int)(unsigned)m_pop, j, mp0[pp]);
+          mp1[pp] = tfx_writelane_i32((int)(unsigned)(m_pop >> 32), j, mp1[pp]);
+          mf0[pp] = tfx_writelane_i32((int)(unsigned)m_far, j, mf0[pp]);
+          mf1[pp] = tfx_writelane_i32((int)(unsigned)(m_far >> 32), j, mf1[pp]);
+          // x of the last car after the move (junk, and unused, when the road is empty)
+          const int tl = n_totj - 1 - pp * 64;
+          if (NP == 1 || (tl >= 0 && tl < 64))
+            r_t = tfx_writelane_i32(__builtin_amdgcn_readlane(__float_as_int(xn), tl > 0 ? tl : 0), j, r_t);
+        }
       };
 
       const unsigned long long sub_spawn = (spawn_mask >> j0) & ((1ull << S) - 1ull);
@@ -284,24 +303,34 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
 
     // ================= phase W: lane j finishes road j ==========================================
     if (run) {
-      const unsigned long long live = lane_mask_below(p.n_tot);
-      const unsigned long long m_pop = ((unsigned long long)(unsigned)mp1 << 32 | (unsigned)mp0) & live;
-      const unsigned long long m_wait = ((unsigned long long)(unsigned)mw1 << 32 | (unsigned)mw0) & live;
-      const unsigned long long m_det = ((unsigned long long)(unsigned)md1 << 32 | (unsigned)md0) & live;
-      const unsigned long long m_far = ((unsigned long long)(unsigned)mf1 << 32 | (unsigned)mf0) & m_pop;
       // cars popped from the head: the while loop (:123) stops at the first car still on the road
-      const int kpop = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+      int kpop = 0, n_wait = 0, n_det = 0;
+      bool open = true, any_far = false;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const unsigned long long live = lane_mask_below(p.n_tot - pp * 64);
+        const unsigned long long m_pop = ((unsigned long long)(unsigned)mp1[pp] << 32 | (unsigned)mp0[pp]) & live;
+        const unsigned long long m_wait = ((unsigned long long)(unsigned)mw1[pp] << 32 | (unsigned)mw0[pp]) & live;
+        const unsigned long long m_det = ((unsigned long long)(unsigned)md1[pp] << 32 | (unsigned)md0[pp]) & live;
+        const unsigned long long m_far = ((unsigned long long)(unsigned)mf1[pp] << 32 | (unsigned)mf0[pp]) & m_pop;
+        const int lead = (~m_pop == 0ull) ? 64 : __builtin_ctzll(~m_pop);
+        if (open) kpop += lead;
+        open = open && lead == 64;  // the whole pass left: the prefix continues in the next one
+        n_wait += __popcll(m_wait);
+        n_det += __popcll(m_det);
+        any_far = any_far || (m_far != 0ull);
+      }
       if (e < d.r) {
         int *ob = d.obs + (size_t)env * d.obs_len;
         if (p.n_tot > 0) {
-          d.waiting[(size_t)env * d.r + e] += __popcll(m_wait);
-          ob[d.r + e] = __popcll(m_det);
+          d.waiting[(size_t)env * d.r + e] += n_wait;
+          ob[d.r + e] = n_det;
         }
         ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, r_t, p.n_tot);
-      if (needs_serial(kpop, m_far != 0ull, p.n_tot, C)) d.env_flag[env] = tick + 1;
+      if (needs_serial(kpop, any_far, p.n_tot, C)) d.env_flag[env] = tick + 1;
       // the leader's x stays in its slot (after the write-back of the image, same wave)
       d.xv[(size_t)id * C + p.ld].x = p.xL;
       my_updates += (unsigned long long)p.n_tot;

@@ -43,17 +43,19 @@ def gap_table(cars_per_tick, tail=1e-12):
 
 
 class PoissonMirror(object):
+    """Draw 0 = the first gap; car c uses draw 1 + 2c for its entry road and draw 2 + 2c for the gap
+    that follows it (the device evaluates 64 cars at a time from these fixed indices)."""
+
     def __init__(self, cars_per_tick, seed, n_entry, env_ids):
         self.cdf = [int(c) for c in gap_table(cars_per_tick)]
         self.k0, self.k1 = int(seed) & MASK, (int(seed) >> 32) & MASK
         self.n_entry = int(n_entry)
         self.env_ids = [int(e) for e in env_ids]
         self.gap = {e: -1 for e in self.env_ids}
-        self.draws = {e: 0 for e in self.env_ids}
+        self.car = {e: 0 for e in self.env_ids}
 
-    def _gap(self, e):
-        u = philox4x32(self.draws[e], e, TAG_GAP, 0, self.k0, self.k1)[0]
-        self.draws[e] += 1
+    def _gap(self, e, draw):
+        u = philox4x32(draw & MASK, e, TAG_GAP, 0, self.k0, self.k1)[0]
         k = 0
         while k < len(self.cdf) - 1 and u >= self.cdf[k]:
             k += 1
@@ -66,13 +68,17 @@ class PoissonMirror(object):
             if e in frozen:
                 continue
             if self.gap[e] < 0:
-                self.gap[e] = self._gap(e)
+                self.gap[e] = self._gap(e, 0)
+            if self.gap[e] > 0:
+                self.gap[e] -= 1
+                continue
             while True:
-                if self.gap[e] > 0:
-                    self.gap[e] -= 1
-                    break
-                u = philox4x32(self.draws[e], e, TAG_ROAD, 0, self.k0, self.k1)[0]
-                self.draws[e] += 1
+                c = self.car[e]
+                u = philox4x32((1 + 2 * c) & MASK, e, TAG_ROAD, 0, self.k0, self.k1)[0]
                 out[row, (u * self.n_entry) >> 32] += 1
-                self.gap[e] = self._gap(e)
+                self.car[e] = c + 1
+                g = self._gap(e, 2 + 2 * c)
+                if g > 0:
+                    self.gap[e] = g - 1
+                    break
         return out

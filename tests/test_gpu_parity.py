@@ -9,6 +9,8 @@ Bars (stated here, asserted below):
     exact for the first 120 ticks free-running (chaotic growth of the <=1-ulp power difference
     afterwards - see tests/test_oracle_golden.py).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -31,7 +33,10 @@ def engine_for(g_or_cfg, n_envs=1, **kw):
                  entry_spec=0b1110 if sc["entry"] == "one" else 0)
     c = dict(c)
     c.update(kw)
-    return TfxEngine(n_envs=n_envs, planes=3, **c)
+    # TFX_TEST_LAYOUT=transposed runs this whole module on the position-major layout (it carries no
+    # spawn-tick plane, so validate-mode cases keep the ring layout)
+    planes = 2 if (os.environ.get("TFX_TEST_LAYOUT") == "transposed" and not c.get("validate")) else 3
+    return TfxEngine(n_envs=n_envs, planes=planes, **c)
 
 
 def oracle_like(eng, **kw):
@@ -70,6 +75,8 @@ def assert_same_state(eng, orc, where=""):
     for k in range(eng.E):
         live = live_mask(ld[k], lc[k], eng.C)
         for plane, name, oplane in ((0, "x", orc.x[k]), (1, "v", orc.v[k]), (2, "w", orc.w[k])):
+            if plane == 2 and eng.w is None:
+                continue
             a, b = st[plane][k][live], oplane[live]
             assert same_bits(a, b), "%s env %d %s" % (name, k, where)
         # the fake leader's x sits in its slot, as in the reference
@@ -88,6 +95,7 @@ def assert_engines_equal(a, b):
         live = live_mask(ld[k], lc[k], a.C)
         for u, v, name in zip(pa, pb, "xvw"):
             assert same_bits(u[k][live], v[k][live]), "%s env %d" % (name, k)
+    assert (a.w is None) == (b.w is None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -168,7 +176,8 @@ def test_teacher_forced_vs_golden(name, golden_cache):
         if live.any():
             assert ulp_diff(sx[live], g["state_x"][k][live]).max() <= 1
             assert ulp_diff(sv[live], g["state_v"][k][live]).max() <= 1
-            assert np.array_equal(sw[live], g["state_w"][k][live])
+            if eng.w is not None:
+                assert np.array_equal(sw[live], g["state_w"][k][live])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -273,11 +282,14 @@ def test_kernel_halves_vs_oracle():
     eng.move_cars()
     orc.elapsed[:] += 1
     orc.move_cars()
-    sx, sv, _ = eng.planes_numpy()
-    for k in range(E):
-        live = live_mask(leading[k], lastcar[k], C)
-        assert same_bits(sx[k][live], orc.x[k][live])
-        assert same_bits(sv[k][live], orc.v[k][live])
+    if eng.layout == "ring":
+        # (the transposed kernel already compacts the roads while it moves the cars, so between
+        # the two halves its cars are not addressable by the not-yet-advanced ring indices)
+        sx, sv, _ = eng.planes_numpy()
+        for k in range(E):
+            live = live_mask(leading[k], lastcar[k], C)
+            assert same_bits(sx[k][live], orc.x[k][live])
+            assert same_bits(sv[k][live], orc.v[k][live])
     assert np.array_equal(eng.waiting.cpu().numpy(), orc.waiting)
     assert np.array_equal(eng.detected.cpu().numpy(), orc.detected)
     eng.advance_finished_cars()

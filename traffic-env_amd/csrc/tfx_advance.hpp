@@ -10,6 +10,7 @@
 // equal the sequential algorithm in every case.
 #pragma once
 #include "tfx_common.hpp"
+#include "tfx_advance_t.hpp"
 
 namespace tfx {
 
@@ -148,6 +149,7 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
   if (overflowed) d.done_tick[env] = tick + 1;
 }
 
+template <bool TL>
 __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
   const int tick = *d.tickB;
   const int n_exit = d.R - d.r;
@@ -160,7 +162,10 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
     if (gid == 0) *d.tickA = tick + 1;
     if (env_frozen(d, env, tick)) continue;  // stopped for the rest of this agent step
     const bool serial = d.env_flag[env] == tick + 1;
-    if (serial && s == 0) advance_env_serial(d, env, tick, tidx);
+    if (serial && s == 0) {
+      if (TL) advance_env_serial_t(d, env, tick, tidx);
+      else advance_env_serial(d, env, tick, tidx);
+    }
     if (s < d.I) {
       // intersection s: its four incoming roads s, I+s, 2I+s, 3I+s (roadgraph.py:38-39)
       int ph_new, el_new;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
 #pragma unroll
         for (int dir = 0; dir < 4; ++dir) {
           const int e = dir * d.I + s;
-          ovf += advance_road(d, env, e, tick, tidx) + d.rec[env * d.R + e].y;
+          ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + d.rec[env * d.R + e].y;
         }
         // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
         float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
       ob[d.I + s] = el_new;
     } else if (!serial) {
       const int e = d.r + (s - d.I);
-      const int ovf = advance_road(d, env, e, tick, tidx);
+      const int ovf = TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx);
       if (ovf > 0) d.done_tick[env] = tick + 1;
       if (d.validate && d.n_trips && s == d.I) {
         // advance_hack :153-154: trip times of cars leaving the map, in road order

@@ -43,7 +43,12 @@ struct Dev {
   int trip_cap;
   // handle-owned tables + scratch
   const int *nexts, *pred, *entry_idx;
-  int4 *rec;      // per road: {pops k | head slot << 8, spawn overflows, bits of post-move tail x, live cars}
+  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows, bits of post-move tail x, live cars}
+  // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this
+  // tick wait in its outbox column; the fake leader's x has no slot of its own and lives in leadx
+  float2 *outb;
+  float *leadx;
+  int layout;
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
   int *env_flag;  // == tick+1 when the env must take the serial advance this tick
   unsigned long long *veh;
@@ -224,9 +229,9 @@ __device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int
 }
 
 // rec.x of a road: number of cars popped this tick (they sit in ring slots head, head+1, ...)
-__device__ __forceinline__ int rec_pack(int kpop, int ld, int C) { return kpop | (wrap1(ld + 1, C) << 8); }
-__device__ __forceinline__ int rec_kpop(int rx) { return rx & 255; }
-__device__ __forceinline__ int rec_head(int rx) { return rx >> 8; }
+__device__ __forceinline__ int rec_pack(int kpop, int ld, int C) { return kpop | (wrap1(ld + 1, C) << 16); }
+__device__ __forceinline__ int rec_kpop(int rx) { return rx & 0xffff; }
+__device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 
 // The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car
 // would itself be popped again downstream this tick, or (c) a full ring pops two or more cars

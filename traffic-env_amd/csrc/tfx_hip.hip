@@ -21,6 +21,7 @@
 #include "tfx_common.hpp"
 #include "tfx_move_generic.hpp"
 #include "tfx_move_dma.hpp"
+#include "tfx_move_t.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_misc.hpp"
 
@@ -67,6 +68,7 @@ struct tfx_handle_s {
   int move_variant = 0;
   size_t move_lds = 0;
   unsigned long long div_mismatches = 0;  // result of the reciprocal-division self-test
+  size_t n_tpairs = 0;                    // (x, v) pairs the xv buffer must hold in the transposed layout
   // fused agent step: the launch sequence of one step, captured once per (ticks, remi, inputs)
   hipGraph_t ag_graph = nullptr;
   hipGraphExec_t ag_exec = nullptr;
@@ -169,7 +171,23 @@ int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
 }
 
 // TFX_MOVE_VARIANT: 0 best known | 1 generic k_move<1> | 20.. tuning points of k_move_dma
+int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
+  const int pvar = h->move_variant;  // TFX_MOVE_VARIANT 52/54/58 = prefetch depth 2/4/8 (default 4)
+  auto go = [&](auto kern) {
+    if (h->grid_move == 0) h->grid_move = move_grid(h, kern, 256);
+    if (h->size_only) return (int)TFX_OK;
+    hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
+    HIPCHK(hipGetLastError());
+    return (int)TFX_OK;
+  };
+  if (pvar == 52) return go(k_move_t<2>);
+  if (pvar == 58) return go(k_move_t<8>);
+  if (pvar == 56) return go(k_move_t<6>);
+  return go(k_move_t<4>);
+}
+
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {
+  if (h->d.layout == 1) return launch_move_t(h, tidx, st);
   const int C = h->d.C;
   const int v = h->move_variant;
   // cfg4: 128-car roads take two passes of a wavefront through the tiled kernel
@@ -239,7 +257,8 @@ int launch_inputs(tfx_handle h, hipStream_t st) {
 int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   const Dev &d = h->d;
   const long items = (long)d.E * (d.I + d.R - d.r);
-  hipLaunchKernelGGL(k_advance, dim3(grid_for(items, h->n_cu)), dim3(256), 0, st, d, tidx);
+  if (d.layout == 1) hipLaunchKernelGGL(k_advance<true>, dim3(grid_for(items, h->n_cu)), dim3(256), 0, st, d, tidx);
+  else hipLaunchKernelGGL(k_advance<false>, dim3(grid_for(items, h->n_cu)), dim3(256), 0, st, d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -336,6 +355,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (cfg->n_envs < 1) return fail(TFX_EINVAL, "n_envs must be >= 1");
   if (cfg->planes != 2 && cfg->planes != 3) return fail(TFX_EINVAL, "planes must be 2 (x,v) or 3 (x,v,w)");
   if (cfg->validate && cfg->planes != 3) return fail(TFX_EINVAL, "validate mode needs planes = 3 (spawn tick w)");
+  if (cfg->layout != 0 && cfg->layout != 1) return fail(TFX_EINVAL, "layout must be 0 (ring) or 1 (transposed)");
+  if (cfg->layout == 1 && cfg->planes != 2) return fail(TFX_EINVAL, "the transposed layout carries (x, v) only: planes must be 2");
   if (cfg->car_delta != 4.0f) return fail(TFX_EINVAL, "only delta = 4 (the reference's archetype) is supported");
   if (!(cfg->length > 0.0f) || !(cfg->rate > 0.0f)) return fail(TFX_EINVAL, "length and rate must be > 0");
   int ndev = 0;
@@ -365,6 +386,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.learn_switch = cfg->learn_switch;
   d.validate = cfg->validate;
   d.env_off = cfg->env_id_offset;
+  d.layout = cfg->layout;
   if (const char *dbg = getenv("TFX_DEBUG")) d.dbg = atoi(dbg);
   d.length = cfg->length;
   d.rate = cfg->rate;
@@ -406,6 +428,9 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec = off;   off = align_up(off + ER * sizeof(int4), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
+  const size_t n_tpairs = ((ER + 63) / 64) * (size_t)(d.C - 2) * 64;  // (x, v) pairs of a transposed array
+  const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
+  const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {
     (void)hipFree(h->dev_tables);
@@ -422,6 +447,9 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.rec = (int4 *)(base + o_rec);
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
+  d.outb = (float2 *)(base + o_outb);
+  d.leadx = (float *)(base + o_lead);
+  h->n_tpairs = n_tpairs;
   d.veh = (unsigned long long *)(base + o_misc);
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
@@ -725,6 +753,33 @@ int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t 
   if (advance_ms) *advance_ms = ad;
   if (n_ticks) *n_ticks = h->ev_used;
   h->ev_used = 0;
+  return TFX_OK;
+}
+
+int tfx_xv_pairs(tfx_handle h, int64_t *pairs) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (!pairs) return fail(TFX_EINVAL, "pairs is null");
+  *pairs = h->d.layout == 1 ? (int64_t)h->n_tpairs : (int64_t)h->d.E * h->d.R * h->d.C;
+  return TFX_OK;
+}
+
+int tfx_export_ring(tfx_handle h, float *ring_xv, void *stream) {
+  if (int rc = check_handle(h, true)) return rc;
+  if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
+  if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
+  hipLaunchKernelGGL(k_export_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
+                     (hipStream_t)stream, h->d, reinterpret_cast<float2 *>(ring_xv));
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int tfx_import_ring(tfx_handle h, const float *ring_xv, void *stream) {
+  if (int rc = check_handle(h, true)) return rc;
+  if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
+  if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
+  hipLaunchKernelGGL(k_import_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
+                     (hipStream_t)stream, h->d, reinterpret_cast<const float2 *>(ring_xv));
+  HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 

@@ -1,6 +1,7 @@
 // tfx_misc.hpp - the cold kernels: reset, tail-cache refresh, remi reward, cars_on_roads, done.
 #pragma once
 #include "tfx_common.hpp"
+#include "tfx_move_t.hpp"
 
 namespace tfx {
 
@@ -11,8 +12,12 @@ __global__ void k_reset(const Dev d, const int *phase_init) {
        id += (long)gridDim.x * blockDim.x) {
     const int env = (int)(id / d.R);
     const int e = (int)(id - (long)env * d.R);
-    d.xv[(size_t)id * d.C + 1] = make_float2(INFINITY, 0.0f);
-    if (d.w) d.w[(size_t)id * d.C + 1] = 0.0f;
+    if (d.layout == 0) {
+      d.xv[(size_t)id * d.C + 1] = make_float2(INFINITY, 0.0f);
+      if (d.w) d.w[(size_t)id * d.C + 1] = 0.0f;
+    } else {
+      d.leadx[id] = INFINITY;
+    }
     d.leading[id] = 1;
     d.lastcar[id] = 1;
     d.tailx[id] = 0.0f;
@@ -39,7 +44,48 @@ __global__ void k_refresh(const Dev d) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x)
-    d.tailx[id] = d.xv[(size_t)id * d.C + d.lastcar[id]].x;
+  {
+    if (d.layout == 0) {
+      d.tailx[id] = d.xv[(size_t)id * d.C + d.lastcar[id]].x;
+    } else {
+      const int n = ring_count(d.leading[id], d.lastcar[id], d.C);
+      d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1)].x : 0.0f;
+    }
+  }
+}
+
+// transposed layout <-> the reference's ring layout ([E][R][C] (x, v) by ring slot, the fake
+// leader's x in slot `leading`): what tfx_export_ring / tfx_import_ring run
+__global__ void k_export_ring(const Dev d, float2 *ring) {
+  const long total = (long)d.E * d.R;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (long)gridDim.x * blockDim.x) {
+    const int ld = d.leading[id];
+    const int n = ring_count(ld, d.lastcar[id], d.C);
+    float2 *row = ring + (size_t)id * d.C;
+    int slot = ld;
+    for (int k = 0; k < n; ++k) {
+      slot = wrap1(slot + 1, d.C);
+      row[slot] = d.xv[tpos(d, (int)id, k)];
+    }
+    row[ld].x = d.leadx[id];
+  }
+}
+
+__global__ void k_import_ring(const Dev d, const float2 *ring) {
+  const long total = (long)d.E * d.R;
+  for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (long)gridDim.x * blockDim.x) {
+    const int ld = d.leading[id];
+    const int n = ring_count(ld, d.lastcar[id], d.C);
+    const float2 *row = ring + (size_t)id * d.C;
+    int slot = ld;
+    for (int k = 0; k < n; ++k) {
+      slot = wrap1(slot + 1, d.C);
+      d.xv[tpos(d, (int)id, k)] = row[slot];
+    }
+    d.leadx[id] = row[ld].x;
+  }
 }
 
 // traffic_env.py:64-78

@@ -1,0 +1,149 @@
+// tfx_move_t.hpp - k_move_t: the move kernel on the TRANSPOSED car layout (tfx_config.layout = 1).
+//
+// Layout: roads are grouped in tiles of 64 consecutive roads; the k-th car behind the fake leader
+// of road j of a tile sits at T[tile][k][j] (position-major, road-minor, (x, v) pairs).  One
+// wavefront owns a tile and lane j walks road j from the head to the tail:
+//   * iteration k loads T[tile][k][0..63]: 64 lanes x 8 B, one fully coalesced 512-byte row,
+//     straight into registers - no LDS, no DMA staging, no ring-slot arithmetic;
+//   * the leader of car k is car k-1 of the same road = the values this lane held one iteration
+//     earlier (Jacobi: the OLD ones), so the follower-gap needs no cross-lane traffic at all;
+//     the fake leader (update_lights :81-94) seeds the chain;
+//   * waiting / detected counts and the pop prefix (advance_finished_cars :123: cars leave from the
+//     head while x > length) are per-lane running values - no ballots, no scans;
+//   * survivors are written back compacted (car k goes to position k - pops so far), cars that left
+//     go to the road's outbox column; both stores are row-shaped and coalesce like the loads;
+//   * rows beyond a road's car count are neither read nor written, so only live cars move.
+// Rows k+1..k+P are in flight while row k is computed (register prefetch).  Per 64 cars this is
+// ~65 vector instructions against ~110 per (up to 64-car) road for the lane-per-car kernels, and
+// the bytes moved are the live ones.  Ring indices (leading/lastcar), counters and every float are
+// bit-identical to the ring-layout kernels; tfx_export_ring / tfx_import_ring convert.
+#pragma once
+#include "tfx_common.hpp"
+
+namespace tfx {
+
+// index of position k of road id in a transposed array (T or the outbox)
+__device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
+  return ((size_t)(id >> 6) * (size_t)(d.C - 2) + (size_t)k) * 64 + (size_t)(id & 63);
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
+  const int C = d.C;
+  const int CAP = C - 2;
+  const long total = (long)d.E * d.R;
+  const long tiles = (total + 63) / 64;
+  const long nw = (long)gridDim.x * 4;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
+    const long base = tile * 64;
+    const bool valid = base + lane < total;
+    const int id = valid ? (int)(base + lane) : (int)(total - 1);
+    const int env = id / d.R;
+    const int e = id - env * d.R;
+    const bool run = valid && !env_frozen(d, env, tick);
+    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
+    const int n_old = run ? p.n_old : 0;
+    const int n_sp = run ? p.n_tot - p.n_old : 0;
+
+    float2 *col = d.xv + ((size_t)tile * CAP) * 64 + lane;     // T[k] of this road = col[k * 64]
+    float2 *ocol = d.outb + ((size_t)tile * CAP) * 64 + lane;  // outbox column of this road
+
+    // longest road of the tile (wave-uniform loop bound)
+    int kmax = n_old;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(kmax, off, 64);
+      kmax = o > kmax ? o : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+
+    // per-road running state
+    float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // leader of the next car: starts as the fake one
+    int kpop = 0, n_wait = 0, n_det = 0, slot = p.ld;
+    bool open = true, far = false;
+    float tail_x = 0.0f;
+    const int lc_seg2 = (p.ld > p.lc) ? p.lc : 0;  // wrapped ring: x, not v, is tested on 1..lastcar (:210)
+
+    // One car of this lane's road.  Runs under `if (active)`: the EXEC mask keeps the running state
+    // of lanes whose road is shorter than the tile's longest untouched.
+    auto step = [&](int k, float x, float v) {
+      float xn, vn;
+      const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
+      if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+      else idm_step(d, x, v, xprev, vprev, llv, xn, vn);
+      xprev = x;  // OLD state leads the next car (Jacobi)
+      vprev = v;
+      llv = d.car_l;
+      slot = (slot + 1 >= C) ? 1 : slot + 1;  // the reference's ring slot of this car
+      const bool pop = open && (xn > d.length);  // the while loop of :123
+      open = pop;
+      far = far || (pop && ((xn - d.length) > d.length));
+      if (pop) ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+      else col[(size_t)(k - kpop) * 64] = make_float2(xn, vn);
+      kpop += pop ? 1 : 0;
+      const float wq = (slot <= lc_seg2) ? xn : vn;
+      n_wait += (wq < d.thresh) ? 1 : 0;
+      n_det += (xn > d.near_end) ? 1 : 0;
+      tail_x = xn;
+    };
+
+    // ---- cars in memory: rows 0 .. kmax-1, P rows in flight ------------------------------------
+    float2 pf[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? col[(size_t)u * 64] : make_float2(0.0f, 0.0f);
+    for (int k0 = 0; k0 < kmax; k0 += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int k = k0 + u;
+        if (k < kmax) {
+          const float2 cur = pf[u];
+          if (k + P < kmax) pf[u] = (k + P < n_old) ? col[(size_t)(k + P) * 64] : make_float2(0.0f, 0.0f);
+          if (k < n_old) step(k, cur.x, cur.y);
+        }
+      }
+    }
+    // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
+    if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
+      int smax = n_sp;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(smax, off, 64);
+        smax = o > smax ? o : smax;
+      }
+      smax = __builtin_amdgcn_readfirstlane(smax);
+      for (int s = 0; s < smax; ++s)
+        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v);
+    }
+
+    // ---- phase W -------------------------------------------------------------------------------
+    if (run) {
+      const int n_tot = p.n_tot;
+      if (e < d.r) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += n_wait;
+          ob[d.r + e] = n_det;
+        }
+        ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+      }
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, __float_as_int(tail_x), n_tot);
+      if (far) d.env_flag[env] = tick + 1;
+      d.leadx[id] = p.xL;
+      my_updates += (unsigned long long)n_tot;
+    }
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+}  // namespace tfx

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib",
 
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TfxConfig(C.Structure):
@@ -20,7 +20,7 @@ class TfxConfig(C.Structure):
                 ("yellow_ticks", C.c_int32), ("thresh", C.c_float), ("detect_dist", C.c_float),
                 ("overflow_penalty", C.c_float), ("eps", C.c_float),
                 ("learn_switch", C.c_int32), ("validate", C.c_int32), ("entry_spec", C.c_uint32),
-                ("env_id_offset", C.c_int32)]
+                ("env_id_offset", C.c_int32), ("layout", C.c_int32)]
 
 
 class TfxBuffers(C.Structure):
@@ -62,6 +62,9 @@ _PROTOS = {
     "tfx_reset_counters": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "tfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "tfx_xv_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tfx_export_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tfx_import_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "tfx_fastdiv_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "tfx_launch_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 3),
 }

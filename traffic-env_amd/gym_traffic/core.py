@@ -7,10 +7,14 @@ HIP kernels through the C ABI (include/tfx.h, csrc/tfx_hip.hip).  Both front-end
 
 State layout = the reference's arrays with a leading env dimension (traffic_env.py:361-382):
     xv [E,R,C,2] f32 ((x, v) per ring slot; `x`/`v` are views)   w [E,R,C] f32 (planes == 3 only)
+    With layout='transposed' (the default when w is not carried) the kernels keep the cars in a
+    position-major array instead (csrc/tfx_move_t.hpp); `xv`/`x`/`v` then are a ring-layout staging
+    copy that is refreshed from the device on access and pushed back by refresh()/load_state().
     leading/lastcar [E,R] i32   obs [E,2r+2I] i32   rewards [E,I] f32   waiting [E,r] i32
     passed_dst [E,I] u8   done_tick [E] i32
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -30,7 +34,8 @@ def _ptr(t):
 
 class TfxEngine(object):
     def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
-                 validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0):
+                 validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0,
+                 layout=None):
         if not torch.cuda.is_available():
             raise nat.TfxError("no GPU visible: the traffic env step runs on MI355X only (no CPU fallback)")
         self.lib = nat.lib()
@@ -47,6 +52,12 @@ class TfxEngine(object):
         cfg.learn_switch, cfg.validate = int(bool(learn_switch)), int(bool(validate))
         cfg.entry_spec = int(entry_spec)
         cfg.env_id_offset = int(env_id_offset)
+        if layout is None:
+            layout = os.environ.get("TFX_LAYOUT") or ("transposed" if self.P == 2 else "ring")
+        if layout not in ("ring", "transposed"):
+            raise ValueError("layout must be 'ring' or 'transposed'")
+        self.layout = layout
+        cfg.layout = 1 if layout == "transposed" else 0
         self.cfg = cfg
         self.validate = bool(validate)
         h = C.c_void_p()
@@ -70,8 +81,13 @@ class TfxEngine(object):
         dev = self.device
         # zeros, not empty: the reference leaves these to np.empty garbage; a defined start keeps
         # runs reproducible (dead slots are never read)
-        self.xv = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
-        self.x, self.v = self.xv[..., 0], self.xv[..., 1]
+        self._ring = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
+        if self.layout == "transposed":
+            pairs = C.c_int64()
+            nat.check(self.lib.tfx_xv_pairs(h, C.byref(pairs)))
+            self._t = torch.zeros((int(pairs.value), 2), dtype=torch.float32, device=dev)
+        else:
+            self._t = None
         self.w = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
         self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
@@ -86,7 +102,7 @@ class TfxEngine(object):
         self.n_trips = torch.zeros((E,), dtype=torch.int32, device=dev) if validate else None
         self._cars = torch.zeros((E, R), dtype=torch.int32, device=dev)
         b = nat.TfxBuffers()
-        b.xv, b.w = _ptr(self.xv), _ptr(self.w)
+        b.xv, b.w = _ptr(self._t if self._t is not None else self._ring), _ptr(self.w)
         b.leading, b.lastcar = _ptr(self.leading), _ptr(self.lastcar)
         b.obs, b.rewards, b.waiting = _ptr(self.obs), _ptr(self.rewards), _ptr(self.waiting)
         b.passed_dst, b.done_tick = _ptr(self.passed_dst), _ptr(self.done_tick)
@@ -104,6 +120,27 @@ class TfxEngine(object):
         self.detected = self.obs[:, r:2 * r]
         self.current_phase = self.obs[:, 2 * r:2 * r + I]
         self.elapsed = self.obs[:, 2 * r + I:]
+
+    # ---- car state in the reference's ring layout -----------------------------------------------
+    def _export(self):
+        if self._t is not None:
+            with torch.cuda.device(self.device):
+                nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), self._stream()))
+
+    @property
+    def xv(self):
+        """[E,R,C,2] (x, v) by ring slot.  Ring layout: the live device array.  Transposed layout: a
+        staging copy brought up to date by this access; write to it, then call refresh()."""
+        self._export()
+        return self._ring
+
+    @property
+    def x(self):
+        return self.xv[..., 0]
+
+    @property
+    def v(self):
+        return self.xv[..., 1]
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -129,7 +166,11 @@ class TfxEngine(object):
         self.done.zero_()
 
     def refresh(self):
+        """After writing xv / leading / lastcar from outside: push the ring-layout staging copy to
+        the device layout (transposed handles) and rebuild the tail cache."""
         with torch.cuda.device(self.device):
+            if self._t is not None:
+                nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), self._stream()))
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 
     def set_poisson(self, cars_per_tick, seed=0):
@@ -281,16 +322,16 @@ class TfxEngine(object):
 
     def planes_numpy(self):
         """(x, v, w) as NumPy [E,R,C] copies (w is zeros when it is not carried)."""
-        x = self.x.cpu().numpy()
-        v = self.v.cpu().numpy()
+        ring = self.xv.cpu().numpy()
+        x, v = ring[..., 0], ring[..., 1]
         w = self.w.cpu().numpy() if self.w is not None else np.zeros_like(x)
         return x, v, w
 
     # ---- bulk state import (tests, checkpoint restore) ----------------------------------------
     def load_state(self, x, v, leading, lastcar, w=None):
         """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
-        self.x.copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
-        self.v.copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
+        self._ring[..., 0].copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
+        self._ring[..., 1].copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
         if self.w is not None and w is not None:
             self.w.copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
         self.leading.copy_(torch.as_tensor(np.asarray(leading, np.int32)).to(self.device))

@@ -70,19 +70,20 @@ def algorithmic_bytes_per_tick(live_cars, roads, intersections):
     return 16 * live_cars + 48 * roads + 32 * intersections
 
 
-def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2):
+def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2, layout=None):
     """A TfxEngine for config `name`, prefilled and switched to the on-device spawn/light rules."""
     import torch
     from gym_traffic.core import TfxEngine
     c = CONFIGS[name]
     E = int(envs if envs is not None else c["envs"])
     eng = TfxEngine(c["m"], c["n"], c["length"], c["capacity"], n_envs=E, rate=0.5, planes=planes,
-                    device=device, env_id_offset=env_id_offset)
+                    device=device, env_id_offset=env_id_offset, layout=layout)
     eng.reset(np.zeros((1, eng.I), np.int32))
     x, v, leading, lastcar = prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
     dev = eng.device
-    eng.x.copy_(torch.as_tensor(x).to(dev)[None].expand_as(eng.x))
-    eng.v.copy_(torch.as_tensor(v).to(dev)[None].expand_as(eng.v))
+    ring = eng.xv                                   # ring-layout view / staging copy
+    ring[..., 0].copy_(torch.as_tensor(x).to(dev)[None].expand_as(ring[..., 0]))
+    ring[..., 1].copy_(torch.as_tensor(v).to(dev)[None].expand_as(ring[..., 1]))
     eng.leading[:] = torch.as_tensor(leading).to(dev)[None]
     eng.lastcar[:] = torch.as_tensor(lastcar).to(dev)[None]
     eng.refresh()

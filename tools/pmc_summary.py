@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_move_dma", "k_move", "k_advance", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads"):
+    for k in ("k_move_dma", "k_move_t", "k_move", "k_advance", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads"):
         if k in name:
             return k
     return None
@@ -59,7 +59,7 @@ def main():
             w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
             for (k, c), v in sorted(agg.items()):
                 w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
-        mv = "k_move_dma" if ("k_move_dma", "FETCH_SIZE") in agg else "k_move"
+        mv = next((k for k in ("k_move_t", "k_move_dma", "k_move") if (k, "FETCH_SIZE") in agg), "k_move")
         if (mv, "FETCH_SIZE") in agg and (mv, "WRITE_SIZE") in agg:
             fetch = sum(agg[(mv, "FETCH_SIZE")]) / len(agg[(mv, "FETCH_SIZE")])
             write = sum(agg[(mv, "WRITE_SIZE")]) / len(agg[(mv, "WRITE_SIZE")])

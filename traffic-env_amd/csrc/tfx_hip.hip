@@ -180,10 +180,20 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return (int)TFX_OK;
   };
+  if (pvar == 61) return go(k_move_t<4, 1>);
+  if (pvar == 62) return go(k_move_t<4, 2>);
+  if (pvar == 63) return go(k_move_t<4, 3>);
   if (pvar == 52) return go(k_move_t<2>);
   if (pvar == 58) return go(k_move_t<8>);
   if (pvar == 56) return go(k_move_t<6>);
-  return go(k_move_t<4>);
+  if (pvar == 54) return go(k_move_t<4>);
+  if (pvar == 66) return go(k_move_t<6, 3>);
+  if (pvar == 68) return go(k_move_t<8, 3>);
+  if (pvar == 64) return go(k_move_t<3, 3>);
+  if (pvar == 65) return go(k_move_t<4, 1>);
+  // every row is read once and written once per tick: non-temporal loads AND stores (0.82 -> 0.70 ms
+  // at cfg2, and the following k_advance no longer waits for dirty lines: 0.057 -> 0.032 ms)
+  return go(k_move_t<4, 3>);
 }
 
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {

@@ -22,12 +22,14 @@
 
 namespace tfx {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
 // index of position k of road id in a transposed array (T or the outbox)
 __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
   return ((size_t)(id >> 6) * (size_t)(d.C - 2) + (size_t)k) * 64 + (size_t)(id & 63);
 }
 
-template <int P>
+template <int P, int NT = 0>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -73,6 +75,24 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
 
     // One car of this lane's road.  Runs under `if (active)`: the EXEC mask keeps the running state
     // of lanes whose road is shorter than the tile's longest untouched.
+    // NT bit 0: non-temporal loads, bit 1: non-temporal stores (every byte is touched once per tick)
+    auto ld2 = [&](const float2 *ptr) {
+      if (NT & 1) {
+        const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ptr));
+        return make_float2(t.x, t.y);
+      }
+      return *ptr;
+    };
+    auto st2 = [&](float2 *ptr, float a, float b) {
+      if (NT & 2) {
+        f2v t;
+        t.x = a;
+        t.y = b;
+        __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(ptr));
+      } else {
+        *ptr = make_float2(a, b);
+      }
+    };
     auto step = [&](int k, float x, float v) {
       float xn, vn;
       const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
@@ -86,7 +106,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       open = pop;
       far = far || (pop && ((xn - d.length) > d.length));
       if (pop) ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-      else col[(size_t)(k - kpop) * 64] = make_float2(xn, vn);
+      else st2(&col[(size_t)(k - kpop) * 64], xn, vn);
       kpop += pop ? 1 : 0;
       const float wq = (slot <= lc_seg2) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
@@ -97,14 +117,14 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     // ---- cars in memory: rows 0 .. kmax-1, P rows in flight ------------------------------------
     float2 pf[P];
 #pragma unroll
-    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? col[(size_t)u * 64] : make_float2(0.0f, 0.0f);
+    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? ld2(&col[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
     for (int k0 = 0; k0 < kmax; k0 += P) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
         const int k = k0 + u;
         if (k < kmax) {
           const float2 cur = pf[u];
-          if (k + P < kmax) pf[u] = (k + P < n_old) ? col[(size_t)(k + P) * 64] : make_float2(0.0f, 0.0f);
+          if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&col[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
           if (k < n_old) step(k, cur.x, cur.y);
         }
       }

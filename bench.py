@@ -90,13 +90,14 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
                       "on %d threads, oracle/idm_oracle.c" % (envs, ticks, name, updates, dt, threads)}
 
 
-def load_pmc_traffic(name):
-    """Per-launch HBM bytes of k_move from the committed rocprofv3 PMC summary, if one exists for
-    this workload (profiles/pmc_<cfg>.json, written by tools/pmc_summary.py)."""
+def load_pmc_traffic(name, kernel):
+    """Per-launch HBM bytes of the move kernel from the committed rocprofv3 PMC summary, if one
+    exists for this workload AND this kernel (profiles/pmc_<cfg>.json, tools/pmc_summary.py)."""
     path = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
     try:
         with open(path) as f:
-            return json.load(f).get("k_move_hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get("k_move_hbm_bytes_per_launch") if d.get("kernel") == kernel else None
     except (OSError, ValueError):
         return None
 
@@ -190,6 +191,7 @@ def main():
         move_bytes = 16.0 * live_per_tick + 48.0 * E * eng.R
         tick_bytes = wl.algorithmic_bytes_per_tick(live_per_tick, E * eng.R, E * eng.I)
         achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
+        kernel = "k_move_t" if eng.layout == "transposed" else "k_move_dma"
         out = {
             "metric": "vehicle_updates_per_sec",
             "value": total_updates / dt_max,
@@ -205,14 +207,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.describe(a.config), "envs_per_gpu": E,
                        "grid": "%dx%d" % (c["m"], c["n"]), "cars_per_road_max": c["capacity"] - 2,
+                       "car_layout": eng.layout,
                        "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of obs/reward/done "
                                                              "to rank 0 every %d ticks" % GATHER_EVERY
                                                              if gather is not None else "")},
             "env_steps_per_sec": world * E * K / dt_max,
             "mean_live_cars_per_road": live_per_tick / (E * eng.R),
-            "roofline": {"bound": "hbm", "kernel": "k_move", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc_traffic(a.config) if E == c["envs"] else None,
+                         "traffic": load_pmc_traffic(a.config, kernel) if E == c["envs"] else None,
                          "algorithmic_bytes_per_launch": move_bytes, "launch_ms": move_ms,
                          "launches_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,

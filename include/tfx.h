@@ -162,8 +162,9 @@ int tfx_advance_finished_cars(tfx_handle h, void *stream);
  * remi_reward() (else the rewards are the sum over the ticks).  Outputs (device pointers, any may
  * be NULL): aobs float32 [E][2r+I] = [sum passed | last detected | elapsed/100*(2*phase-1)],
  * areward float32 [E][I], adone uint8 [E].  The launch sequence is captured into a HIP graph on
- * first use and replayed afterwards.  Needs actions and spawns that do not change per tick on the
- * host (one held action buffer or the cycle rule; no spawns, the periodic rule, or one count buffer). */
+ * first use and replayed afterwards.  Needs ONE action for the whole step (a held buffer, the cycle
+ * rule or the greedy controller); any spawn rule works, a per-tick count buffer must hold at least
+ * n_ticks rows (row t feeds tick t of the step; rows after an env's overflow are not consumed). */
 int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
                    uint8_t *adone, void *stream);
 

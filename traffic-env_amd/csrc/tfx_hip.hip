@@ -318,16 +318,16 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
                               uint8_t *adone, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (n_ticks < 1) return fail(TFX_EINVAL, "n_ticks < 1");
-  if (h->action_per_tick || h->spawn_per_tick)
-    return fail(TFX_EINVAL, "the fused agent step holds one action for all its ticks and needs a spawn rule "
-                            "that does not advance on the host (none, periodic, or one fixed count buffer)");
+  if (h->action_per_tick)
+    return fail(TFX_EINVAL, "the fused agent step holds ONE action for all its ticks (bind the action buffer "
+                            "with per_tick = 0)");
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
   if (!h->use_graph) return agent_sequence(h, n_ticks, remi, aobs, areward, adone, st);
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[512];
-  snprintf(key, sizeof key, "%d%d%d|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", (int)h->poisson,
-           (int)h->greedy, h->greedy_spacing, n_ticks, remi, (void *)aobs,
+  snprintf(key, sizeof key, "%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", (int)h->poisson,
+           (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, (void *)aobs,
            (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
            (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
            (void *)d.rewards, (void *)d.leading, (void *)d.lastcar, (void *)d.waiting, (void *)d.done_tick);

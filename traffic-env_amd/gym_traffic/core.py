@@ -220,15 +220,22 @@ class TfxEngine(object):
         elif counts is not None:
             c = self._to_dev_i32(counts)
             if per_tick:
+                # same-shaped schedules re-use one device buffer, so the pointer (and a captured
+                # agent-step graph keyed on it) stays valid from call to call
+                # (a caller's own device tensor is bound as it is: zero copy)
+                if (not isinstance(counts, torch.Tensor) and self._spawn_buf is not None
+                        and self._spawn_bound == "per_tick" and self._spawn_buf.shape == c.shape):
+                    self._spawn_buf.copy_(c)
+                    return
                 self._spawn_buf = c
-                self._spawn_bound = False
+                self._spawn_bound = "per_tick"
                 nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1))
                 return
             if self._held_spawn is None or self._held_spawn.shape != c.shape:
                 self._held_spawn = torch.empty_like(c)
                 self._spawn_bound = False
             self._held_spawn.copy_(c)
-            if not self._spawn_bound:
+            if self._spawn_bound is not True:
                 nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(self._held_spawn), 0, 0))
                 self._spawn_bound = True
         else:

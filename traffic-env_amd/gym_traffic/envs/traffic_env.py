@@ -262,6 +262,70 @@ class TrafficEnv(gym.Env):
                 self.trip_times.extend(eng.trip_times[0, ntrips:new].cpu().numpy())
         return self.obs, self.rewards, overflowed, None
 
+    def repeat(self, action, n_ticks):
+        """`n_ticks` x `_step(action)` exactly as the Repeater wrapper drives it (reference
+        traffic_test.py:36-53: passed summed, detected of the last tick, signed elapsed/100, rewards
+        summed, `if done: break`) as ONE device submission (tfx_agent_step, replayed as a HIP graph)
+        instead of n_ticks host round trips.  Returns (total_obs float32[2r+I], total_reward
+        float32[I], done).  Afterwards the env is in the state the tick-by-tick loop leaves it in,
+        except that `self.passed` / `self.rewards` hold the step's sums rather than the last
+        tick's values (`Remi` overwrites the latter anyway)."""
+        self._sync_flags()
+        eng, n = self.engine, int(n_ticks)
+        if getattr(self, '_rep_counts', None) is None or self._rep_counts.shape[0] != n:
+            self._rep_counts = np.zeros((n, 1, max(1, eng.n_entry)), np.int32)
+        sched_marks, made = [], []
+        for t in range(n):
+            sched_marks.append(self._mark_spawner())
+            roads = self._spawns()
+            made.append(len(roads))
+            counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._rep_counts[t, 0])
+        eng.set_spawns(counts=self._rep_counts, per_tick=True)
+        act = np.asarray(action)
+        if flag('learn_switch', False):
+            act = (act != 0)
+        eng.set_actions(act.astype(np.int32).reshape(1, -1))
+        first = eng.tick
+        ntrips = int(eng.n_trips[0]) if self._validate else 0
+        aobs, arew, adone = eng.agent_step(n, remi=False)
+        total_obs = aobs[0].cpu().numpy()
+        total_reward = arew[0].cpu().numpy()
+        done = bool(adone[0].item())
+        ran = n
+        if done:
+            # the loop broke after the overflowing tick: un-draw the arrivals of the ticks that
+            # never ran and put the device clock where `steps` is
+            ran = int(eng.done_tick[0].item()) - first
+            if ran < n:
+                self._rewind_spawner(sched_marks[ran])
+                eng.set_tick(first + ran)
+        self.steps += ran
+        self.generated_cars += sum(made[:ran])
+        self._pull()
+        if self._validate:
+            new = int(eng.n_trips[0])
+            if new > ntrips:
+                self.trip_times.extend(eng.trip_times[0, ntrips:new].cpu().numpy())
+        return total_obs, total_reward, done
+
+    def _mark_spawner(self):
+        s = getattr(self, '_schedule', None)
+        if s is None:
+            if not hasattr(self, 'rand'):
+                self.seed_generator()
+            return (self.rand.get_state(), None)
+        return (s.rand.get_state(), (s._started, s._gap, s._i))
+
+    def _rewind_spawner(self, mark):
+        state, inner = mark
+        self.rand.set_state(state)
+        s = getattr(self, '_schedule', None)
+        if s is not None:
+            if inner is None:
+                self._schedule = None
+            else:
+                s._started, s._gap, s._i = inner
+
     def _pull(self):
         eng = self.engine
         self.obs[:] = eng.obs[0].cpu().numpy()

@@ -78,6 +78,26 @@ class TrafficVecEnv(object):
             eng.step(int(n_ticks))
         return eng.obs, eng.rewards, eng.done
 
+    def agent_step(self, actions=None, n_ticks=10, remi=True, cycle_period=None):
+        """One agent decision for every env as ONE device submission: the Repeater (+ Remi) wrappers
+        of the reference (traffic_test.py:27-64) fused in tfx_agent_step.  Returns device tensors
+        (aobs f32 [E,2r+I], areward f32 [E,I], adone u8 [E]) owned by the engine.  An env that
+        overflows stands still for the rest of the decision (`if done: break`); with host-side
+        arrival schedules the arrivals drawn for its remaining ticks are dropped."""
+        eng, n = self.engine, int(n_ticks)
+        if cycle_period is not None:
+            eng.set_actions(cycle_period=cycle_period)
+        elif actions is not None:
+            eng.set_actions(actions)
+        if self.spawn in ('poisson', 'regular'):
+            if getattr(self, '_tick_counts', None) is None or self._tick_counts.shape[0] != n:
+                self._tick_counts = np.zeros((n,) + self._counts.shape, np.int32)
+            for t in range(n):
+                for k, s in enumerate(self._sched):
+                    counts_from_roads(s.next_tick(), eng.entry_index, eng.n_entry, out=self._tick_counts[t, k])
+            eng.set_spawns(counts=self._tick_counts, per_tick=True)
+        return eng.agent_step(n, remi=remi)
+
     def remi_reward(self):
         return self.engine.remi_reward()
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 3
+#define TFX_ABI_VERSION 4
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -200,6 +200,12 @@ int tfx_import_ring(tfx_handle h, const float *ring_xv, void *stream);
 int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches);
 /* launch geometry of the move kernel, for the roofline report */
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
+/* Ticks of this handle that tfx_step ran fused, several per launch with the cars held in LDS (k_line),
+ * since tfx_create, and whether the handle's storage order allows it at all (`capable`: transposed
+ * layout with every street line inside one wavefront).  tfx_step fuses on its own whenever it is
+ * asked for >= 2 ticks, the spawn rule and the controller do not depend on the cars (no on-device
+ * Poisson / greedy), and validate mode is off; results are bit-identical either way. */
+int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
 
 #ifdef __cplusplus
 }

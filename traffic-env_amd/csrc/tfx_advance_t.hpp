@@ -29,14 +29,15 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
     const int k_p = rec_kpop(d.rec[idp].x);
     if (k_p > 0) {
       const int ld_seen = (p < e) ? ld : ld_post;
+      const size_t pcol = tcol(d, env, p), ecol = tcol(d, env, e);
       for (int j = 0; j < k_p; ++j) {
-        const float2 car = d.outb[tpos(d, idp, j)];
+        const float2 car = d.outb[pcol + (size_t)j * 64];
         const float xc = car.x - d.length;  // state[e,xi,newlead] -= length (:130)
         const int pos = wrap1(lc + 1, C);
         const float start = (lc != ld_seen) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
         if (pos != ld_seen) {
           const float xv = (start < xc) ? start : xc;
-          d.xv[tpos(d, id, m)] = make_float2(xv, car.y);
+          d.xv[ecol + (size_t)m * 64] = make_float2(xv, car.y);
           ++m;
           lc = pos;
           tail_x = xv;

@@ -43,6 +43,12 @@ struct Dev {
   int trip_cap;
   // handle-owned tables + scratch
   const int *nexts, *pred, *entry_idx;
+  // transposed layout: road e of an env lives in storage slot road_slot[e] (tile = slot / 64, lane =
+  // slot % 64, G tiles per env); slot_road is the inverse (-1 = padding lane).  With `lines` set the
+  // slots follow the street lines (entry road -> ... -> exit road on consecutive lanes, whole lines
+  // per tile), which is what lets k_line run many ticks of a tile without leaving the wavefront.
+  const int *road_slot, *slot_road;
+  int G, lines;
   int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows, bits of post-move tail x, live cars}
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this
   // tick wait in its outbox column; the fake leader's x has no slot of its own and lives in leadx
@@ -142,10 +148,8 @@ __device__ __forceinline__ bool env_frozen(const Dev &d, int env, int tick) {
 }
 
 // TrafficEnv._step lines :225-232 for one intersection: new phase and elapsed from the old ones.
-__device__ __forceinline__ void light_update(const Dev &d, int env, int i, int tick, int tidx,
-                                             int &ph_new, int &el_new) {
-  const int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
-  const int ph = ob[i], el = ob[d.I + i];
+__device__ __forceinline__ void light_next(const Dev &d, int env, int i, int tick, int tidx, int ph, int el,
+                                           int &ph_new, int &el_new) {
   int a;
   if (d.action_mode == TFX_ACTION_CYCLE)
     a = ((tick + (env + d.env_off) % d.action_period) / d.action_period) & 1;
@@ -162,6 +166,11 @@ __device__ __forceinline__ void light_update(const Dev &d, int env, int i, int t
     ph_new = a;
   }
   el_new = change ? 0 : el + 1;
+}
+__device__ __forceinline__ void light_update(const Dev &d, int env, int i, int tick, int tidx,
+                                             int &ph_new, int &el_new) {
+  const int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+  light_next(d, env, i, tick, tidx, ob[i], ob[d.I + i], ph_new, el_new);
 }
 
 // cars add_new_cars (traffic_env.py:274-283) puts on entry road e (entry index ej) this tick

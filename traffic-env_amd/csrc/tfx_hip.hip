@@ -22,6 +22,7 @@
 #include "tfx_move_generic.hpp"
 #include "tfx_move_dma.hpp"
 #include "tfx_move_t.hpp"
+#include "tfx_line.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_misc.hpp"
 
@@ -56,14 +57,21 @@ struct tfx_handle_s {
   int n_cu = 256;
   int wpr = 1;
   int grid_move = 0;
-  std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx;
-  int *dev_tables = nullptr;  // nexts | pred | entry_idx
+  std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
+  int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
+  int tiles_per_env = 0;      // G: 64-slot tiles one env occupies in the transposed layout
+  bool lines = false;         // slots follow the street lines (k_line can fuse ticks)
+  int fuse_ticks = 10;        // ticks one k_line launch runs (TFX_FUSE_TICKS; 0/1 = never fuse)
   void *dev_scratch = nullptr;
   int32_t action_per_tick = 0, spawn_per_tick = 0;
   // optional per-kernel timing with HIP events on the launch stream (tfx_profile)
   std::vector<hipEvent_t> ev;
   int ev_ticks = 0, ev_used = 0;
+  std::vector<int> ev_weight;  // ticks the i-th timed entry covers (1, or the ticks of a fused launch)
   bool prof = false;
+  long long fused_ticks = 0;   // ticks run by k_line since tfx_create
+  int grid_line = 0;           // k_line: blocks resident at once
+  size_t line_lds = 0;
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
   size_t move_lds = 0;
@@ -121,6 +129,48 @@ void build_tables(tfx_handle_s *h) {
   for (size_t j = 0; j < h->h_entry.size(); ++j) h->h_entry_idx[h->h_entry[j]] = (int)j;
 }
 
+// Storage slots of the transposed layout.  A street line = an entry road followed through `nexts`
+// to its exit road (roadgraph.py:54-64: cars never turn, so lines share nothing but the lights).
+// With TFX_LINES=1 and every line fitting a wavefront, whole lines are packed into each 64-slot
+// tile, consecutive roads of a line on consecutive lanes; otherwise slots are road ids.
+void build_slots(tfx_handle_s *h) {
+  const int R = (int)h->h_nexts.size(), r = 4 * h->cfg.m * h->cfg.n;
+  std::vector<std::vector<int>> lines;
+  std::vector<char> seen(R, 0);
+  for (int e = 0; e < r; ++e) {
+    if (h->h_pred[e] >= 0) continue;
+    lines.emplace_back();
+    for (int q = e; q >= 0; q = h->h_nexts[q]) {
+      lines.back().push_back(q);
+      seen[q] = 1;
+    }
+  }
+  size_t longest = 0;
+  bool all = true;
+  for (auto &l : lines) longest = l.size() > longest ? l.size() : longest;
+  for (int e = 0; e < R; ++e) all = all && seen[e];
+  // Opt-in (TFX_LINES=1): measured at cfg2 the fused kernel this order enables is LDS-capacity bound
+  // (4 wavefronts per CU, 1.7 ms per tick against 0.71 ms for the streaming kernels) and the
+  // per-road words of column lines stop coalescing in the per-tick kernels.
+  const char *lv = getenv("TFX_LINES");
+  h->lines = all && longest >= 1 && longest <= 64 && lv && atoi(lv) != 0;
+  if (h->lines) {
+    const int per_tile = 64 / (int)longest;
+    h->tiles_per_env = ((int)lines.size() + per_tile - 1) / per_tile;
+    h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
+    for (size_t li = 0; li < lines.size(); ++li)
+      for (size_t q = 0; q < lines[li].size(); ++q)
+        h->h_slot_road[(li / per_tile) * 64 + (li % per_tile) * longest + q] = lines[li][q];
+  } else {
+    h->tiles_per_env = (R + 63) / 64;
+    h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
+    for (int e = 0; e < R; ++e) h->h_slot_road[e] = e;
+  }
+  h->h_road_slot.assign(R, -1);
+  for (size_t s = 0; s < h->h_slot_road.size(); ++s)
+    if (h->h_slot_road[s] >= 0) h->h_road_slot[h->h_slot_road[s]] = (int)s;
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 int check_handle(tfx_handle h, bool need_bound) {
@@ -136,8 +186,11 @@ int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds 
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess || per_cu < 1)
     per_cu = 4;
-  if (per_cu > 8) per_cu = 8;
-  const long total = (long)h->d.E * h->d.R;
+  // more resident waves than ~5 blocks per CU only adds concurrent DRAM streams: measured at cfg2
+  // 3/4/5/6/7/8 blocks per CU -> 0.763/0.721/0.711/0.720/0.804/0.761 ms
+  if (per_cu > 5) per_cu = 5;
+  if (const char *pc = getenv("TFX_MOVE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+  const long total = h->d.layout == 1 ? (long)h->d.E * h->d.G * 64 : (long)h->d.E * h->d.R;
   const long need = (total + work_items_per_block - 1) / work_items_per_block;
   long g = (long)h->n_cu * per_cu;
   if (g > need) g = need;
@@ -185,6 +238,9 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   if (pvar == 63) return go(k_move_t<4, 3>);
   if (pvar == 52) return go(k_move_t<2>);
   if (pvar == 58) return go(k_move_t<8>);
+  if (pvar == 72) return go(k_move_t<12>);
+  if (pvar == 76) return go(k_move_t<16>);
+  if (pvar == 77) return go(k_move_t<16, 3>);
   if (pvar == 56) return go(k_move_t<6>);
   if (pvar == 54) return go(k_move_t<4>);
   if (pvar == 66) return go(k_move_t<6, 3>);
@@ -261,6 +317,41 @@ int launch_inputs(tfx_handle h, hipStream_t st) {
                        h->dev_greedy, h->greedy_spacing);
     HIPCHK(hipGetLastError());
   }
+  return TFX_OK;
+}
+
+// k_line: LDS ring rows per road (power of two >= C - 2) and the launch
+int line_rows(tfx_handle h) {
+  int rows = 1;
+  while (rows < h->d.C - 2) rows <<= 1;
+  return rows;
+}
+size_t line_lds_bytes(tfx_handle h) { return (size_t)line_rows(h) * 64 * sizeof(float2); }
+
+int launch_line(tfx_handle h, int tidx0, int n_ticks, hipStream_t st, hipEvent_t *ev = nullptr) {
+  const Dev &d = h->d;
+  if (h->grid_line == 0) {
+    h->line_lds = line_lds_bytes(h);
+    if (h->line_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void *)k_line, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->line_lds));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_line, 64, h->line_lds) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    const long tiles = (long)d.E * d.G;
+    long g = (long)h->n_cu * per_cu;
+    if (const char *gm = getenv("TFX_LINE_GRID")) g = (long)h->n_cu * atoi(gm);
+    h->grid_line = (int)(g > tiles ? tiles : (g < 1 ? 1 : g));
+  }
+  // rewards[:] = 0 (:233): the last tick's overflow penalties are added by the road lanes
+  HIPCHK(hipMemsetAsync(d.rewards, 0, (size_t)d.E * d.I * sizeof(float), st));
+  if (ev) HIPCHK(hipEventRecord(ev[0], st));
+  hipLaunchKernelGGL(k_line, dim3(h->grid_line), dim3(64), h->line_lds, st, d, tidx0, n_ticks, line_rows(h) - 1);
+  HIPCHK(hipGetLastError());
+  if (ev) HIPCHK(hipEventRecord(ev[1], st));
+  hipLaunchKernelGGL(k_line_lights, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d, tidx0, n_ticks);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, d, n_ticks);
+  HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
@@ -376,6 +467,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (!h) return fail(TFX_ENOMEM, "out of host memory");
   h->cfg = *cfg;
   build_tables(h);
+  build_slots(h);
+  if (const char *ft = getenv("TFX_FUSE_TICKS")) h->fuse_ticks = atoi(ft);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   int dev = 0;
@@ -417,13 +510,16 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
 
   // tables
   const size_t R = (size_t)d.R;
-  if (hipMalloc((void **)&h->dev_tables, 3 * R * sizeof(int)) != hipSuccess) {
+  const size_t n_slots = h->h_slot_road.size();
+  if (hipMalloc((void **)&h->dev_tables, (4 * R + n_slots) * sizeof(int)) != hipSuccess) {
     delete h;
     return fail(TFX_ENOMEM, "hipMalloc(tables) failed");
   }
   if (hipMemcpy(h->dev_tables, h->h_nexts.data(), R * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(h->dev_tables + R, h->h_pred.data(), R * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(h->dev_tables + 2 * R, h->h_entry_idx.data(), R * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(h->dev_tables + 2 * R, h->h_entry_idx.data(), R * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->dev_tables + 3 * R, h->h_road_slot.data(), R * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->dev_tables + 4 * R, h->h_slot_road.data(), n_slots * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(h->dev_tables);
     delete h;
     return fail(TFX_EDEVICE, "uploading the road tables failed");
@@ -431,6 +527,10 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.nexts = h->dev_tables;
   d.pred = h->dev_tables + R;
   d.entry_idx = h->dev_tables + 2 * R;
+  d.road_slot = h->dev_tables + 3 * R;
+  d.slot_road = h->dev_tables + 4 * R;
+  d.G = h->tiles_per_env;
+  d.lines = h->lines ? 1 : 0;
 
   // scratch
   const size_t ER = (size_t)d.E * R;
@@ -438,7 +538,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec = off;   off = align_up(off + ER * sizeof(int4), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
-  const size_t n_tpairs = ((ER + 63) / 64) * (size_t)(d.C - 2) * 64;  // (x, v) pairs of a transposed array
+  const size_t n_tpairs = (size_t)d.E * d.G * (size_t)(d.C - 2) * 64;  // (x, v) pairs of a transposed array
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
@@ -646,9 +746,24 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (n_ticks < 0) return fail(TFX_EINVAL, "n_ticks < 0");
   hipStream_t st = (hipStream_t)stream;
+  // whole street lines per wavefront, inputs that do not depend on the cars: fuse ticks in k_line
+  const bool fuse = h->lines && h->d.layout == 1 && !h->poisson && !h->greedy && !h->d.validate &&
+                    !h->d.agent_mode && h->fuse_ticks >= 2 && line_lds_bytes(h) <= 160 * 1024;
   for (int t = 0; t < n_ticks; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    const int chunk = n_ticks - t < h->fuse_ticks ? n_ticks - t : h->fuse_ticks;
+    if (fuse && chunk >= 2) {
+      if (int rc = launch_line(h, t, chunk, st, e)) return rc;
+      h->fused_ticks += chunk;
+      if (timed) {
+        HIPCHK(hipEventRecord(e[2], st));
+        h->ev_weight[h->ev_used] = chunk;
+        ++h->ev_used;
+      }
+      t += chunk - 1;
+      continue;
+    }
     if (int rc = launch_inputs(h, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[0], st));
     if (int rc = launch_move(h, t, st)) return rc;
@@ -656,6 +771,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     if (int rc = launch_advance(h, t, st)) return rc;
     if (timed) {
       HIPCHK(hipEventRecord(e[2], st));
+      h->ev_weight[h->ev_used] = 1;
       ++h->ev_used;
     }
   }
@@ -743,6 +859,7 @@ int tfx_profile(tfx_handle h, int32_t max_ticks) {
   h->prof = max_ticks > 0;
   if (!h->prof) return TFX_OK;
   h->ev.resize((size_t)max_ticks * 3);
+  h->ev_weight.assign((size_t)max_ticks, 1);
   for (hipEvent_t &e : h->ev) HIPCHK(hipEventCreate(&e));
   h->ev_ticks = max_ticks;
   return TFX_OK;
@@ -751,6 +868,7 @@ int tfx_profile(tfx_handle h, int32_t max_ticks) {
 int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t *n_ticks) {
   if (int rc = check_handle(h, false)) return rc;
   double mv = 0.0, ad = 0.0;
+  int ticks = 0;
   for (int i = 0; i < h->ev_used; ++i) {
     float a = 0.f, b = 0.f;
     HIPCHK(hipEventSynchronize(h->ev[(size_t)i * 3 + 2]));
@@ -758,10 +876,11 @@ int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t 
     HIPCHK(hipEventElapsedTime(&b, h->ev[(size_t)i * 3 + 1], h->ev[(size_t)i * 3 + 2]));
     mv += a;
     ad += b;
+    ticks += h->ev_weight[i];
   }
   if (move_ms) *move_ms = mv;
   if (advance_ms) *advance_ms = ad;
-  if (n_ticks) *n_ticks = h->ev_used;
+  if (n_ticks) *n_ticks = ticks;
   h->ev_used = 0;
   return TFX_OK;
 }
@@ -797,6 +916,13 @@ int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches) {
   if (int rc = check_handle(h, false)) return rc;
   if (enabled) *enabled = h->d.fastdiv;
   if (mismatches) *mismatches = h->div_mismatches;
+  return TFX_OK;
+}
+
+int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (ticks) *ticks = h->fused_ticks;
+  if (capable) *capable = (h->lines && h->d.layout == 1 && h->fuse_ticks >= 2) ? 1 : 0;
   return TFX_OK;
 }
 

@@ -24,9 +24,15 @@ namespace tfx {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-// index of position k of road id in a transposed array (T or the outbox)
+// index of position 0 of road e of env in a transposed array (T or the outbox); position k is 64 k
+// pairs further
+__device__ __forceinline__ size_t tcol(const Dev &d, int env, int e) {
+  const int s = d.road_slot[e];
+  return ((size_t)env * d.G + (size_t)(s >> 6)) * (size_t)(d.C - 2) * 64 + (size_t)(s & 63);
+}
 __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
-  return ((size_t)(id >> 6) * (size_t)(d.C - 2) + (size_t)k) * 64 + (size_t)(id & 63);
+  const int env = id / d.R;
+  return tcol(d, env, id - env * d.R) + (size_t)k * 64;
 }
 
 template <int P, int NT = 0>
@@ -36,19 +42,18 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   const int tick = *d.tickA;
   const int C = d.C;
   const int CAP = C - 2;
-  const long total = (long)d.E * d.R;
-  const long tiles = (total + 63) / 64;
+  const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
 
   unsigned long long my_updates = 0;
 
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
-    const long base = tile * 64;
-    const bool valid = base + lane < total;
-    const int id = valid ? (int)(base + lane) : (int)(total - 1);
-    const int env = id / d.R;
-    const int e = id - env * d.R;
+    const int env = (int)(tile / d.G);  // a tile never straddles envs
+    const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+    const bool valid = e_slot >= 0;
+    const int e = valid ? e_slot : 0;
+    const int id = env * d.R + e;
     const bool run = valid && !env_frozen(d, env, tick);
     const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
     const int n_old = run ? p.n_old : 0;

@@ -322,6 +322,12 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_fastdiv_status(self.h, C.byref(en), C.byref(bad)))
         return dict(enabled=bool(en.value), mismatches=int(bad.value))
 
+    def fused_ticks(self):
+        """(ticks tfx_step has run fused in k_line so far, whether this handle can fuse at all)."""
+        n, cap = C.c_int64(), C.c_int32()
+        nat.check(self.lib.tfx_fused_ticks(self.h, C.byref(n), C.byref(cap)))
+        return int(n.value), bool(cap.value)
+
     def launch_info(self):
         v = [C.c_int32() for _ in range(3)]
         nat.check(self.lib.tfx_launch_info(self.h, *[C.byref(x) for x in v]))

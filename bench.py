@@ -85,9 +85,20 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
             break
     dt = time.perf_counter() - t0
     updates = orc.vehicle_updates - base
+    # the same sample on ONE thread for a few seconds (report both ratios)
+    base1 = orc.vehicle_updates
+    t1 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t1 < 3.0 and k < max_ticks:
+        orc.step(*sched[(3 + ticks + k) % period], nthreads=1)
+        k += 1
+    dt1 = time.perf_counter() - t1
+    one = (orc.vehicle_updates - base1) / dt1
     return {"value": updates / dt, "unit": "vehicle-updates/s", "cores": threads, "kind": "port",
+            "one_core_value": one,
             "sample": "%d envs x %d ticks of %s (%.3g vehicle-updates in %.1f s), OpenMP over envs "
-                      "on %d threads, oracle/idm_oracle.c" % (envs, ticks, name, updates, dt, threads)}
+                      "on %d threads, oracle/idm_oracle.c; then %d ticks on 1 thread (%.1f s)"
+                      % (envs, ticks, name, updates, dt, threads, k, dt1)}
 
 
 def load_pmc_traffic(name, kernel):
@@ -212,6 +223,7 @@ def main():
                                                              "to rank 0 every %d ticks" % GATHER_EVERY
                                                              if gather is not None else "")},
             "env_steps_per_sec": world * E * K / dt_max,
+            "agent_steps_per_sec": world * E * K / dt_max / GATHER_EVERY,   # one decision = 10 ticks
             "mean_live_cars_per_road": live_per_tick / (E * eng.R),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

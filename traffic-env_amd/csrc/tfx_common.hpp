@@ -49,6 +49,7 @@ struct Dev {
   // per tile), which is what lets k_line run many ticks of a tile without leaving the wavefront.
   const int *road_slot, *slot_road;
   int G, lines;
+  int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T and in the outbox: >= C - 2
   int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows, bits of post-move tail x, live cars}
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this
   // tick wait in its outbox column; the fake leader's x has no slot of its own and lives in leadx

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void k_line(const Dev d, const int tidx0, const
     const bool has_pred = pe >= 0;           // the predecessor is lane - 1
     const bool pred_lower = has_pred && pe < e;
 
-    float2 *col = d.xv + ((size_t)tile * CAP) * 64 + lane;
+    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
     int *ob = d.obs + (size_t)env * d.obs_len;
 
     int ld = valid ? d.leading[id] : 1, lc = valid ? d.lastcar[id] : 1;

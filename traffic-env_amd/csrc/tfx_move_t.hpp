@@ -28,7 +28,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 // pairs further
 __device__ __forceinline__ size_t tcol(const Dev &d, int env, int e) {
   const int s = d.road_slot[e];
-  return ((size_t)env * d.G + (size_t)(s >> 6)) * (size_t)(d.C - 2) * 64 + (size_t)(s & 63);
+  return ((size_t)env * d.G + (size_t)(s >> 6)) * (size_t)d.trows * 64 + (size_t)(s & 63);
 }
 __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
   const int env = id / d.R;
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     const int n_old = run ? p.n_old : 0;
     const int n_sp = run ? p.n_tot - p.n_old : 0;
 
-    float2 *col = d.xv + ((size_t)tile * CAP) * 64 + lane;     // T[k] of this road = col[k * 64]
-    float2 *ocol = d.outb + ((size_t)tile * CAP) * 64 + lane;  // outbox column of this road
+    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;     // T[k] of this road = col[k * 64]
+    float2 *ocol = d.outb + ((size_t)tile * d.trows) * 64 + lane;  // outbox column of this road
 
     // longest road of the tile (wave-uniform loop bound)
     int kmax = n_old;

@@ -238,6 +238,9 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   if (pvar == 63) return go(k_move_t<4, 3>);
   if (pvar == 52) return go(k_move_t<2>);
   if (pvar == 58) return go(k_move_t<8>);
+  if (pvar == 84) return go(k_move_t<4, 3, true>);
+  if (pvar == 86) return go(k_move_t<6, 3, true>);
+  if (pvar == 88) return go(k_move_t<8, 3, true>);
   if (pvar == 72) return go(k_move_t<12>);
   if (pvar == 76) return go(k_move_t<16>);
   if (pvar == 77) return go(k_move_t<16, 3>);

@@ -39,7 +39,6 @@ __global__ __launch_bounds__(64) void k_line(const Dev d, const int tidx0, const
   extern __shared__ float2 ring[];
   const int lane = threadIdx.x;
   const int C = d.C;
-  const int CAP = C - 2;
   const long tiles = (long)d.E * d.G;
   const int tick0 = *d.tickA;  // advanced by k_tick_add after this kernel, never inside it
   unsigned long long my_updates = 0;

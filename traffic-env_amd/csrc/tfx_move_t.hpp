@@ -35,13 +35,16 @@ __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
   return tcol(d, env, id - env * d.R) + (size_t)k * 64;
 }
 
-template <int P, int NT = 0>
+// BATCH: the walk proceeds in groups of P rows - the P loads of the next group are issued back to
+// back, the group is computed, its P stores are issued back to back - instead of one load and one
+// store per row (longer same-direction bursts at the memory side; tools/copy_probe.hip measures
+// 5.8 TB/s for 4-row and 6.1 TB/s for 8-row groups on this access shape)
+template <int P, int NT = 0, bool BATCH = false>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
   const int C = d.C;
-  const int CAP = C - 2;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
@@ -98,20 +101,29 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         *ptr = make_float2(a, b);
       }
     };
+    float2 outv[P];  // BATCH: survivors of the current group and their destination rows (-1: none)
+    int outrow[P];
+    int ucur = 0;
     auto step = [&](int k, float x, float v) {
       float xn, vn;
       const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
-      if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+      if (d.dbg & 64) {  // timing ablation: no arithmetic (results are wrong)
+        xn = x;
+        vn = v;
+      } else if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
       else idm_step(d, x, v, xprev, vprev, llv, xn, vn);
       xprev = x;  // OLD state leads the next car (Jacobi)
       vprev = v;
       llv = d.car_l;
       slot = (slot + 1 >= C) ? 1 : slot + 1;  // the reference's ring slot of this car
-      const bool pop = open && (xn > d.length);  // the while loop of :123
+      const bool pop = open && (xn > d.length) && !(d.dbg & 128);  // the while loop of :123 (128: ablation)
       open = pop;
       far = far || (pop && ((xn - d.length) > d.length));
       if (pop) ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-      else st2(&col[(size_t)(k - kpop) * 64], xn, vn);
+      else if (BATCH) {
+        outv[ucur] = make_float2(xn, vn);
+        outrow[ucur] = k - kpop;
+      } else st2(&col[(size_t)(k - kpop) * 64], xn, vn);
       kpop += pop ? 1 : 0;
       const float wq = (slot <= lc_seg2) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
@@ -123,17 +135,43 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     float2 pf[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? ld2(&col[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
-    for (int k0 = 0; k0 < kmax; k0 += P) {
+    if (BATCH) {
+      for (int k0 = 0; k0 < kmax; k0 += P) {
+        float2 cur[P];
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int k = k0 + u;
-        if (k < kmax) {
-          const float2 cur = pf[u];
-          if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&col[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
-          if (k < n_old) step(k, cur.x, cur.y);
+        for (int u = 0; u < P; ++u) {
+          cur[u] = pf[u];
+          outrow[u] = -1;
+        }
+        if (k0 + P < kmax) {
+#pragma unroll
+          for (int u = 0; u < P; ++u)
+            pf[u] = (k0 + P + u < n_old) ? ld2(&col[(size_t)(k0 + P + u) * 64]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int k = k0 + u;
+          ucur = u;
+          if (k < n_old) step(k, cur[u].x, cur[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+          if (outrow[u] >= 0) st2(&col[(size_t)outrow[u] * 64], outv[u].x, outv[u].y);
+      }
+    } else {
+      for (int k0 = 0; k0 < kmax; k0 += P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int k = k0 + u;
+          if (k < kmax) {
+            const float2 cur = pf[u];
+            if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&col[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+            if (k < n_old) step(k, cur.x, cur.y);
+          }
         }
       }
     }
+    ucur = 0;
     // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
     if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
       int smax = n_sp;
@@ -143,8 +181,11 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         smax = o > smax ? o : smax;
       }
       smax = __builtin_amdgcn_readfirstlane(smax);
-      for (int s = 0; s < smax; ++s)
+      for (int s = 0; s < smax; ++s) {
+        if (BATCH) outrow[0] = -1;
         if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v);
+        if (BATCH && outrow[0] >= 0) st2(&col[(size_t)outrow[0] * 64], outv[0].x, outv[0].y);
+      }
     }
 
     // ---- phase W -------------------------------------------------------------------------------

@@ -189,3 +189,19 @@ def test_philox_known_answer_and_gap_table():
     p25 = gap_table(2.5).astype(np.float64) / 2 ** 32
     rate = 1.0 / (1.0 - p25).sum()
     assert abs(tot[0].sum() / 600.0 - rate) < 0.25 * rate and not np.array_equal(tot[0], tot[1])
+
+
+def test_spawn_schedule_shortcuts_consume_the_stream_like_the_literal_calls():
+    """SpawnSchedule draws `randint(0, len(a))` for the reference's `rand.choice(a)` and skips
+    `rand.randint(1)`: both must leave a legacy RandomState exactly where the literal calls do."""
+    ent = np.array([0, 4, 8, 12, 19, 23, 27, 31, 32, 33, 34, 35, 60, 61, 62, 63], np.int32)
+    for seed in range(20):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        for _ in range(100):
+            gap_a, gap_b = a.exponential(0.37), b.exponential(0.37)
+            a.randint(1)                                   # the reference's archetypes[randint(1)]
+            road_a = a.choice(ent)                         # add_new_cars: rand.choice(entrypoints)
+            road_b = ent[b.randint(0, len(ent))]
+            assert gap_a == gap_b and road_a == road_b
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]

@@ -32,6 +32,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class HostMirror(object):
+    def __init__(self, device, tensors):
+        self.device = device
+        self.dev = list(tensors)
+        self.host = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.dev]
+        self.views = [h.numpy() for h in self.host]
+
+    def pull(self):
+        for h, t in zip(self.host, self.dev):
+            h.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.views
+
+
 class TfxEngine(object):
     def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
                  validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0,
@@ -113,7 +127,8 @@ class TfxEngine(object):
         self._held_action = None
         self._held_spawn = None
         self._action_bound = None
-        self._spawn_bound = False
+        self._spawn_bound = None
+        self._stages = {}
         self.tick = 0
         # views with the reference's attribute names (traffic_env.py:372-376)
         self.passed = self.obs[:, :r]
@@ -180,7 +195,7 @@ class TfxEngine(object):
         cdf = gap_table(cars_per_tick)
         nat.check(self.lib.tfx_set_poisson(self.h, float(cars_per_tick), int(seed),
                                            cdf.ctypes.data_as(C.c_void_p), int(cdf.size)))
-        self._spawn_bound = False
+        self._spawn_bound = None
 
     def set_greedy(self, spacing=3):
         """On-device greedy controller (algorithms/greedy.py:14-16), a decision every `spacing` ticks."""
@@ -189,63 +204,81 @@ class TfxEngine(object):
 
     def set_actions(self, actions=None, cycle_period=None, per_tick=False):
         """actions: int tensor/array [E,I] (or [I] broadcast; with per_tick a leading n_ticks
-        dim), or cycle_period for the on-device fixed cycle.  Held (non per-tick) actions are copied
-        into a buffer the engine keeps, so the device pointer - and any captured graph - stays valid."""
+        dim), or cycle_period for the on-device fixed cycle.  Host arrays go through a pinned staging
+        buffer into a device buffer the engine keeps per shape, held device tensors are copied into
+        one, so the bound pointer - and any captured graph - stays valid from call to call; a
+        per-tick device tensor is bound as it is (zero copy)."""
         if cycle_period is not None:
             nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_CYCLE, None, int(cycle_period), 0))
             self._action_bound = None
             return
-        a = self._to_dev_i32(actions)
+        a, owned = self._as_dev_i32(actions, "act_pt" if per_tick else "act")
         if per_tick:
             mode = nat.ACTION_BROADCAST if a.dim() == 2 else nat.ACTION_BUFFER
-            self._action_buf = a
-            self._action_bound = None
-            nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, 1))
-            return
-        mode = nat.ACTION_BROADCAST if a.dim() == 1 else nat.ACTION_BUFFER
-        if self._held_action is None or self._held_action.shape != a.shape:
-            self._held_action = torch.empty_like(a)
-            self._action_bound = None
-        self._held_action.copy_(a)
-        if self._action_bound != mode:
-            nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(self._held_action), 0, 0))
-            self._action_bound = mode
+            key = ("per_tick", mode, a.data_ptr())
+        else:
+            mode = nat.ACTION_BROADCAST if a.dim() == 1 else nat.ACTION_BUFFER
+            if not owned:
+                if self._held_action is None or self._held_action.shape != a.shape:
+                    self._held_action = torch.empty_like(a)
+                self._held_action.copy_(a)
+                a = self._held_action
+            key = ("held", mode, a.data_ptr())
+        self._action_buf = a
+        if self._action_bound != key:
+            nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, 1 if per_tick else 0))
+            self._action_bound = key
 
     def set_spawns(self, counts=None, period=None, per_tick=False):
         """counts: int [E,n_entry] (with per_tick: [n_ticks,E,n_entry]); period: on-device
-        one-car-every-`period`-ticks per entry road; neither: no spawns."""
+        one-car-every-`period`-ticks per entry road; neither: no spawns.  Buffers as in set_actions."""
         if period is not None:
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_PERIODIC, None, int(period), 0))
-            self._spawn_bound = False
+            self._spawn_bound = None
         elif counts is not None:
-            c = self._to_dev_i32(counts)
+            c, owned = self._as_dev_i32(counts, "spawn_pt" if per_tick else "spawn")
             if per_tick:
-                # same-shaped schedules re-use one device buffer, so the pointer (and a captured
-                # agent-step graph keyed on it) stays valid from call to call
-                # (a caller's own device tensor is bound as it is: zero copy)
-                if (not isinstance(counts, torch.Tensor) and self._spawn_buf is not None
-                        and self._spawn_bound == "per_tick" and self._spawn_buf.shape == c.shape):
-                    self._spawn_buf.copy_(c)
-                    return
-                self._spawn_buf = c
-                self._spawn_bound = "per_tick"
-                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1))
-                return
-            if self._held_spawn is None or self._held_spawn.shape != c.shape:
-                self._held_spawn = torch.empty_like(c)
-                self._spawn_bound = False
-            self._held_spawn.copy_(c)
-            if self._spawn_bound is not True:
-                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(self._held_spawn), 0, 0))
-                self._spawn_bound = True
+                key = ("per_tick", c.data_ptr())
+            else:
+                if not owned:
+                    if self._held_spawn is None or self._held_spawn.shape != c.shape:
+                        self._held_spawn = torch.empty_like(c)
+                    self._held_spawn.copy_(c)
+                    c = self._held_spawn
+                key = ("held", c.data_ptr())
+            self._spawn_buf = c
+            if self._spawn_bound != key:
+                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1 if per_tick else 0))
+                self._spawn_bound = key
         else:
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_NONE, None, 0, 0))
-            self._spawn_bound = False
+            self._spawn_bound = None
 
-    def _to_dev_i32(self, a):
+    def _as_dev_i32(self, a, key):
+        """-> (int32 device tensor, owned).  Device tensors pass through (owned False).  Host arrays
+        are written to a pinned staging buffer and copied asynchronously into a device buffer kept
+        per (key, shape): `owned` True - the engine may bind that buffer itself."""
         if isinstance(a, torch.Tensor):
-            return a.to(device=self.device, dtype=torch.int32).contiguous()
-        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+            return a.to(device=self.device, dtype=torch.int32).contiguous(), False
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        slot = self._stages.get((key, a.shape))
+        if slot is None:
+            slot = [torch.empty(a.shape, dtype=torch.int32).pin_memory(),
+                    torch.empty(a.shape, dtype=torch.int32, device=self.device), torch.cuda.Event(), False]
+            self._stages[(key, a.shape)] = slot
+        pin, dev, ev, used = slot
+        if used:
+            ev.synchronize()            # the previous upload from this staging buffer has left the host
+        pin.numpy()[...] = a
+        dev.copy_(pin, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[3] = True
+        return dev, True
+
+    def host_mirror(self, *tensors):
+        """Pinned host copies of small device tensors, refreshed together with ONE stream
+        synchronisation: mirror.pull() -> list of NumPy views (valid until the next pull)."""
+        return HostMirror(self.device, tensors)
 
     def step(self, n_ticks=1):
         """n_ticks x TrafficEnv._step (traffic_env.py:224-248) with the inputs set by

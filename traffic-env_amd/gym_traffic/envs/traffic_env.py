@@ -178,6 +178,11 @@ class TrafficEnv(gym.Env):
         self.waiting = DeviceView(lambda: eng.waiting[0])
         self.passed_dst = DeviceView(lambda: eng.passed_dst[0], dtype=np.bool_)
         self._spawn_counts = np.zeros((1, max(1, eng.n_entry)), np.int32)
+        # read-backs go through pinned mirrors: one stream synchronisation per step / per decision
+        tail = [eng.n_trips] if self._validate else []
+        self._mirror = eng.host_mirror(eng.obs, eng.rewards, eng.done, *tail)
+        self._mirror_rep = None
+        self._trips_seen = 0
 
     def _sync_flags(self):
         """The reference re-reads FLAGS.rate / learn_switch / mode on every tick (traffic_env.py:
@@ -237,6 +242,7 @@ class TrafficEnv(gym.Env):
         self.steps = np.float32(0)
         self.generated_cars = 0
         self.engine.reset(self.action_space.sample())
+        self._trips_seen = 0
         self._pull()
         return self.obs
 
@@ -252,14 +258,9 @@ class TrafficEnv(gym.Env):
         if flag('learn_switch', False):
             act = (act != 0)
         eng.set_actions(act.astype(np.int32).reshape(1, -1))
-        ntrips = int(eng.n_trips[0]) if self._validate else 0
         eng.step(1)
         self.steps += 1
         overflowed = self._pull()
-        if self._validate:
-            new = int(eng.n_trips[0])
-            if new > ntrips:
-                self.trip_times.extend(eng.trip_times[0, ntrips:new].cpu().numpy())
         return self.obs, self.rewards, overflowed, None
 
     def repeat(self, action, n_ticks):
@@ -274,9 +275,9 @@ class TrafficEnv(gym.Env):
         eng, n = self.engine, int(n_ticks)
         if getattr(self, '_rep_counts', None) is None or self._rep_counts.shape[0] != n:
             self._rep_counts = np.zeros((n, 1, max(1, eng.n_entry)), np.int32)
-        sched_marks, made = [], []
+        mark = self._mark_spawner()
+        made = []
         for t in range(n):
-            sched_marks.append(self._mark_spawner())
             roads = self._spawns()
             made.append(len(roads))
             counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._rep_counts[t, 0])
@@ -286,26 +287,29 @@ class TrafficEnv(gym.Env):
             act = (act != 0)
         eng.set_actions(act.astype(np.int32).reshape(1, -1))
         first = eng.tick
-        ntrips = int(eng.n_trips[0]) if self._validate else 0
         aobs, arew, adone = eng.agent_step(n, remi=False)
-        total_obs = aobs[0].cpu().numpy()
-        total_reward = arew[0].cpu().numpy()
-        done = bool(adone[0].item())
+        if self._mirror_rep is None:
+            tail = [eng.n_trips] if self._validate else []
+            self._mirror_rep = eng.host_mirror(aobs, arew, adone, eng.obs, eng.rewards, eng.done_tick, *tail)
+        got = self._mirror_rep.pull()
+        total_obs, total_reward = got[0][0].copy(), got[1][0].copy()
+        done = bool(got[2][0])
         ran = n
         if done:
             # the loop broke after the overflowing tick: un-draw the arrivals of the ticks that
             # never ran and put the device clock where `steps` is
-            ran = int(eng.done_tick[0].item()) - first
+            ran = int(got[5][0]) - first
             if ran < n:
-                self._rewind_spawner(sched_marks[ran])
+                self._rewind_spawner(mark)
+                for _ in range(ran):
+                    self._spawns()
                 eng.set_tick(first + ran)
         self.steps += ran
         self.generated_cars += sum(made[:ran])
-        self._pull()
+        self.obs[:] = got[3][0]
+        self.rewards[:] = got[4][0]
         if self._validate:
-            new = int(eng.n_trips[0])
-            if new > ntrips:
-                self.trip_times.extend(eng.trip_times[0, ntrips:new].cpu().numpy())
+            self._collect_trips(int(got[6][0]))
         return total_obs, total_reward, done
 
     def _mark_spawner(self):
@@ -327,10 +331,20 @@ class TrafficEnv(gym.Env):
                 s._started, s._gap, s._i = inner
 
     def _pull(self):
-        eng = self.engine
-        self.obs[:] = eng.obs[0].cpu().numpy()
-        self.rewards[:] = eng.rewards[0].cpu().numpy()
-        return bool(eng.done[0].item())
+        """Refresh the live host buffers (obs, rewards) from the device; returns the done flag.  In
+        validate mode also collects the trip times recorded since the last pull."""
+        got = self._mirror.pull()
+        self.obs[:] = got[0][0]
+        self.rewards[:] = got[1][0]
+        if self._validate:
+            self._collect_trips(int(got[3][0]))
+        return bool(got[2][0])
+
+    def _collect_trips(self, n_now):
+        seen = getattr(self, '_trips_seen', 0)
+        if n_now > seen:
+            self.trip_times.extend(self.engine.trip_times[0, seen:n_now].cpu().numpy())
+        self._trips_seen = n_now
 
     def cars_on_roads(self):
         return self.engine.cars_on_roads()[0].cpu().numpy()

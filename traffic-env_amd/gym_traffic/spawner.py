@@ -5,6 +5,10 @@ generators of the reference and the entry-road draw of `add_new_cars` (traffic_e
 :274-283), so that `seed_generator(seed)` yields the same (tick, road) sequence as the reference -
 "identical seeds/spawns".  RNG draws per car, in order: `exponential` (gap to the next car, Poisson
 only), `randint(n_archetypes)`, `choice(entrypoints)`.  The device only ever sees per-tick counts.
+
+Two of those calls are issued in a cheaper, stream-identical form (tests/test_host_logic.py checks
+both against the literal calls): `choice(a)` of a 1-D array draws `randint(0, len(a))` and indexes,
+and `randint(1)` - the archetype pick with the reference's single archetype - consumes nothing.
 """
 import math
 
@@ -43,18 +47,18 @@ class SpawnSchedule(object):
             if self._gap > 0:
                 self._gap -= 1
                 return n
-            self.rand.randint(self.n_archetypes)   # archetype pick (one archetype: always 0)
+            if self.n_archetypes > 1:
+                self.rand.randint(self.n_archetypes)   # archetype pick
             self._gap = None
             n += 1
-            yield_road = self.rand.choice(self.entrypoints)
-            self._roads.append(int(yield_road))
+            self._roads.append(int(self.entrypoints[self.rand.randint(0, len(self.entrypoints))]))
 
     def _regular_tick(self):
         due = self._every == 0 or self._i % self._every == 0
         self._i += 1
         if due:
             for _ in range(self._burst):
-                self._roads.append(int(self.rand.choice(self.entrypoints)))
+                self._roads.append(int(self.entrypoints[self.rand.randint(0, len(self.entrypoints))]))
 
     def next_tick(self):
         """Entry roads of the cars created this tick, in creation order."""

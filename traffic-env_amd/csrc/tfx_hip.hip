@@ -22,6 +22,7 @@
 #include "tfx_move_generic.hpp"
 #include "tfx_move_dma.hpp"
 #include "tfx_move_t.hpp"
+#include "tfx_move_ts.hpp"
 #include "tfx_line.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_misc.hpp"
@@ -233,6 +234,28 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return (int)TFX_OK;
   };
+  // Launches too small to fill the chip with one wavefront per tile: four wavefronts per tile
+  // (TFX_MOVE_VARIANT 90 forces it, 91 forbids it)
+  const long tiles = (long)h->d.E * h->d.G;
+  // measured (ms per launch, k_move_t -> k_move_ts): cfg2 x 16 envs (272 tiles) 0.055 -> 0.020, cfg4 x 1
+  // (260) 0.075 -> 0.028, cfg1 x 256 (320) 0.023 -> 0.016, cfg4 x 4 (1040 tiles of 128 rows) 0.102 ->
+  // 0.083; no gain at cfg2 x 64 (1088) and a loss at cfg1 x 1024 (1280): there the redundant road
+  // prologues outweigh the shorter walks
+  const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
+  if (pvar == 90 || (pvar == 0 && tiles <= split_below)) {
+    auto gs = [&](auto kern) {
+      if (h->grid_move == 0) h->grid_move = (int)(tiles < (long)h->n_cu * 8 ? tiles : (long)h->n_cu * 8);
+      if (h->size_only) return (int)TFX_OK;
+      hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
+      HIPCHK(hipGetLastError());
+      return (int)TFX_OK;
+    };
+    const int cap = h->d.C - 2;
+    if (cap <= 32) return gs(k_move_ts<8>);
+    if (cap <= 64) return gs(k_move_ts<16>);
+    if (cap <= 128) return gs(k_move_ts<32>);
+    return gs(k_move_ts<64>);
+  }
   if (pvar == 61) return go(k_move_t<4, 1>);
   if (pvar == 62) return go(k_move_t<4, 2>);
   if (pvar == 63) return go(k_move_t<4, 3>);

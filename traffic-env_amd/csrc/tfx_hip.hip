@@ -224,9 +224,10 @@ int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
   return TFX_OK;
 }
 
-// TFX_MOVE_VARIANT: 0 best known | 1 generic k_move<1> | 20.. tuning points of k_move_dma
+// Transposed layout.  TFX_MOVE_VARIANT: 0 = automatic | 54/58/68/88 k_move_t A/B points | 90/91 force /
+// forbid the four-waves-per-tile kernel
 int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
-  const int pvar = h->move_variant;  // TFX_MOVE_VARIANT 52/54/58 = prefetch depth 2/4/8 (default 4)
+  const int pvar = h->move_variant;
   auto go = [&](auto kern) {
     if (h->grid_move == 0) h->grid_move = move_grid(h, kern, 256);
     if (h->size_only) return (int)TFX_OK;
@@ -256,28 +257,17 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     if (cap <= 128) return gs(k_move_ts<32>);
     return gs(k_move_ts<64>);
   }
-  if (pvar == 61) return go(k_move_t<4, 1>);
-  if (pvar == 62) return go(k_move_t<4, 2>);
-  if (pvar == 63) return go(k_move_t<4, 3>);
-  if (pvar == 52) return go(k_move_t<2>);
+  // A/B points kept from the tuning runs
+  if (pvar == 54) return go(k_move_t<4>);           // default caching policy (0.82 ms at cfg2)
   if (pvar == 58) return go(k_move_t<8>);
-  if (pvar == 84) return go(k_move_t<4, 3, true>);
-  if (pvar == 86) return go(k_move_t<6, 3, true>);
-  if (pvar == 88) return go(k_move_t<8, 3, true>);
-  if (pvar == 72) return go(k_move_t<12>);
-  if (pvar == 76) return go(k_move_t<16>);
-  if (pvar == 77) return go(k_move_t<16, 3>);
-  if (pvar == 56) return go(k_move_t<6>);
-  if (pvar == 54) return go(k_move_t<4>);
-  if (pvar == 66) return go(k_move_t<6, 3>);
   if (pvar == 68) return go(k_move_t<8, 3>);
-  if (pvar == 64) return go(k_move_t<3, 3>);
-  if (pvar == 65) return go(k_move_t<4, 1>);
+  if (pvar == 88) return go(k_move_t<8, 3, true>);  // loads and stores in 8-row groups
   // every row is read once and written once per tick: non-temporal loads AND stores (0.82 -> 0.70 ms
   // at cfg2, and the following k_advance no longer waits for dirty lines: 0.057 -> 0.032 ms)
   return go(k_move_t<4, 3>);
 }
 
+// Ring layout.  TFX_MOVE_VARIANT: 0 = automatic | 1 generic k_move<1> | 21/24/26/34 k_move_dma A/B points
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (h->d.layout == 1) return launch_move_t(h, tidx, st);
   const int C = h->d.C;
@@ -294,23 +284,11 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (v == 0 && (long)h->d.E * h->d.R < 64L * h->n_cu) return launch_generic<1>(h, tidx, st);
   if (C == 34) return launch_dma<34, 8, 2, 4, false, 2>(h, tidx, st);   // cfg1
   if (C != 66 || v == 26) return launch_dma<0, 8, 1, 8, false>(h, tidx, st);  // capacity read at run time
-  switch (v) {  // C == 66 (cfg2): tuning points
-    case 20: return launch_dma<66, 8, 1, 8, false>(h, tidx, st);
-    case 22: return launch_dma<66, 8, 2, 4, false>(h, tidx, st);
-    case 23: return launch_dma<66, 4, 2, 4, false>(h, tidx, st);
-    case 24: return launch_dma<66, 8, 2, 8, true>(h, tidx, st);
-    case 25: return launch_dma<66, 16, 2, 8, false>(h, tidx, st);
-    case 27: return launch_dma<66, 8, 2, 2, false>(h, tidx, st);
-    case 28: return launch_dma<66, 16, 1, 8, false>(h, tidx, st);
-    case 29: return launch_dma<66, 8, 2, 1, false>(h, tidx, st);
-    case 31: return launch_dma<66, 8, 2, 8, false, 1>(h, tidx, st);
-    case 32: return launch_dma<66, 8, 2, 8, false, 2>(h, tidx, st);
-    case 33: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);
-    case 34: return launch_dma<66, 8, 3, 8, false, 2>(h, tidx, st);
-    case 35: return launch_dma<66, 4, 3, 4, false, 2>(h, tidx, st);
-    case 36: return launch_dma<66, 4, 2, 4, false, 2>(h, tidx, st);
-    case 21: return launch_dma<66, 8, 2, 8, false>(h, tidx, st);
-    default: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);  // best measured
+  switch (v) {  // C == 66 (cfg2): A/B points kept from the tuning runs
+    case 21: return launch_dma<66, 8, 2, 8, false>(h, tidx, st);      // whole image written back
+    case 24: return launch_dma<66, 8, 2, 8, true>(h, tidx, st);       // leader through LDS instead of DPP
+    case 34: return launch_dma<66, 8, 3, 8, false, 2>(h, tidx, st);   // three sub-tiles in flight
+    default: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);   // best measured
   }
 }
 

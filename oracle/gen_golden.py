@@ -42,7 +42,7 @@ def scen(name, **kw):
     SCENARIOS[name] = d
 
 
-for _s in (0, 1):
+for _s in (0, 1, 2, 3):
     for _p in (True, False):
         for _c in (10, 20):
             scen("g2x2_s%d_%s_c%d" % (_s, "poi" if _p else "reg", _c), seed=_s, poisson=_p, C=_c,

@@ -409,3 +409,30 @@ def test_reciprocal_division_selftest():
     eng = engine_for(dict(m=2, n=2, length=100.0, capacity=10, rate=0.5))
     st = eng.fastdiv_status()
     assert st["mismatches"] == 0 and st["enabled"]
+
+
+@pytest.mark.parametrize("m,n,C", [(1, 1, 3), (1, 3, 3), (3, 1, 4), (1, 1, 258), (2, 1, 5)])
+def test_minimal_and_maximal_shapes_vs_oracle(m, n, C):
+    """The corners of the parameter space: one-intersection and one-row grids, rings that hold a
+    single car (CAPACITY 3 = scratch slot + fake leader + one car), the largest ring (256 cars)."""
+    rng = np.random.RandomState(77 + 7 * m + n + C)
+    E, length = 3, 45.0
+    eng = engine_for(dict(m=m, n=n, length=length, capacity=C, rate=0.5), n_envs=E)
+    orc = oracle_like(eng)
+    ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    dones = 0
+    for t in range(90):
+        act = rng.randint(2, size=(E, eng.I)).astype(np.int32) if t % 5 == 0 else act
+        roads = [rng.choice(eng.entrypoints, size=rng.randint(0, 3)).tolist() for _ in range(E)]
+        eng.set_spawns(counts=counts(eng, roads))
+        eng.set_actions(act)
+        eng.step(1)
+        _, _, odone = orc.step(act, roads)
+        assert np.array_equal(eng.done.cpu().numpy(), odone), t
+        dones += int(odone.sum())
+        if t % 6 == 0 or t == 89:
+            assert_same_state(eng, orc, "tick %d" % t)
+    if C <= 5:
+        assert dones > 0        # single-car rings overflow all the time: the penalty path ran

@@ -39,6 +39,100 @@ __global__ __launch_bounds__(256) void k_rw(V *__restrict__ a, V *__restrict__ b
 }
 
 
+// k_model: the same in-place stream with k_move_t's features switched on one by one
+//   RAGGED  per-lane road lengths 40..56 rows (partial rows at the tails)
+//   SHIFT   one lane in ten writes its rows one row up (NOT representative of k_move_t's compaction:
+//           the kernel itself is no faster with the shift ablated, TFX_DEBUG-style test; not timed)
+//   WORDS   per tile: 8 dependent-free word loads per lane before the walk, 5 word stores after it
+//   MATH    ~70 dependent float operations (one true division) between a row's load and its store
+template <int U, bool RAGGED, bool SHIFT, bool WORDS, bool MATH>
+__global__ __launch_bounds__(256) void k_model(f2 *__restrict__ a, int *__restrict__ words, size_t n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  for (size_t t = wave; t < n_tiles; t += nwaves) {
+    f2 *col = a + t * 4096 + lane;  // 64 rows x 64 lanes
+    unsigned h = (unsigned)(t * 64 + lane) * 2654435761u;
+    int n = RAGGED ? 40 + (int)((h >> 8) % 17u) : 48;
+    const int shift = (SHIFT && ((h >> 20) % 10u) == 0) ? 1 : 0;
+    float acc = 0.f;
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+      int s0 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s0 += w[q * n_tiles * 64];
+      n += (s0 & 0);  // keep the loads alive, leave n unchanged
+      acc = (float)(s0 & 1);
+    }
+    int kmax = n;
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(kmax, off, 64);
+      kmax = o > kmax ? o : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    f2 pf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pf[u] = (u < n) ? __builtin_nontemporal_load(col + (size_t)u * 64) : f2{0, 0};
+    float px = 1e9f, pv = 0.f;
+    for (int k0 = 0; k0 < kmax; k0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        if (k < kmax) {
+          f2 c = pf[u];
+          if (k + U < kmax) pf[u] = (k + U < n) ? __builtin_nontemporal_load(col + (size_t)(k + U) * 64) : f2{0, 0};
+          if (k < n) {
+            f2 o = c;
+            if (MATH) {
+              float s = px - c.x - 4.f, q = c.y * 0.072f;
+              float st = 1.f + c.y * 2.f + c.y * (c.y - pv) * 0.1178f;
+              float r = st / (s + 1e-8f);
+              float dv = 3.f * (1.f - q * q * q * q - r * r);
+#pragma unroll
+              for (int z = 0; z < 12; ++z) dv = dv * 0.999f + 0.001f * r;  // stand-in for the bookkeeping chain
+              o.x = c.x + fmaxf(0.f, 0.5f * c.y + 0.125f * dv);
+              o.y = fmaxf(0.f, c.y + 0.5f * dv);
+              px = c.x;
+              pv = c.y;
+            } else {
+              o.x = c.x * 1.0001f + 0.5f;
+            }
+            const int row = (k - shift < 0) ? 0 : k - shift;
+            __builtin_nontemporal_store(o, col + (size_t)row * 64);
+            acc += o.x;
+          }
+        }
+      }
+    }
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) w[(8 + q) * n_tiles * 64] = (int)acc + q;
+    }
+  }
+}
+
+#define MODEL(label, U, RG, SH, WD, MA, grid)                                                      \
+  do {                                                                                            \
+    const size_t n_tiles = bytes / 32768;                                                         \
+    hipEvent_t s, e;                                                                              \
+    hipEventCreate(&s);                                                                           \
+    hipEventCreate(&e);                                                                           \
+    for (int i = 0; i < 2; ++i)                                                                   \
+      hipLaunchKernelGGL((k_model<U, RG, SH, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(s);                                                                            \
+    for (int i = 0; i < 10; ++i)                                                                  \
+      hipLaunchKernelGGL((k_model<U, RG, SH, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(e);                                                                            \
+    hipEventSynchronize(e);                                                                       \
+    float ms = 0;                                                                                 \
+    hipEventElapsedTime(&ms, s, e);                                                               \
+    ms /= 10;                                                                                     \
+    printf("model %-38s grid %5d: %.3f ms\n", label, grid, ms);                                   \
+    hipEventDestroy(s);                                                                           \
+    hipEventDestroy(e);                                                                           \
+  } while (0)
+
 #define TIME(label, V, U, NT, INP, grid)                                                          \
   do {                                                                                            \
     const size_t n_vec = bytes / sizeof(V);                                                       \
@@ -81,6 +175,15 @@ int main(int argc, char **argv) {
     TIME("in place, 16 B/lane, 4 rows", f4, 4, false, true, g);
     TIME("a -> b, 16 B/lane, 4 rows, nt", f4, 4, true, false, g);
     TIME("a -> b, 8 B/lane, 4 rows, nt", f2, 4, true, false, g);
+  }
+  // 48 of 64 rows live per road, as in the benchmark: every model line moves ~2.75 GB
+  {
+    const int g = cu * 5;
+    MODEL("48 rows per road, 4 in flight", 4, false, false, false, false, g);
+    MODEL("road lengths 40..56 (ragged tails)", 4, true, false, false, false, g);
+    MODEL("48 rows + per-road words", 4, false, false, true, false, g);
+    MODEL("48 rows + arithmetic", 4, false, false, false, true, g);
+    MODEL("ragged + words + arithmetic", 4, true, false, true, true, g);
   }
   hipFree(a);
   hipFree(b);

@@ -279,8 +279,7 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (h->wpr == 4) return launch_generic<4>(h, tidx, st);
   if ((C & 1) || v == 1) return launch_generic<1>(h, tidx, st);  // odd capacity: records not 16-B multiples
   // fewer roads than one 64-road tile per CU: the tiled kernel would leave most CUs idle and walk
-  // its tile serially; one wavefront per road finishes sooner (measured: cfg0 96 -> 69 us, cfg1 x 16
-  // envs 210 -> 87 us per 10-tick agent step)
+  // its tile serially; one wavefront per road finishes sooner
   if (v == 0 && (long)h->d.E * h->d.R < 64L * h->n_cu) return launch_generic<1>(h, tidx, st);
   if (C == 34) return launch_dma<34, 8, 2, 4, false, 2>(h, tidx, st);   // cfg1
   if (C != 66 || v == 26) return launch_dma<0, 8, 1, 8, false>(h, tidx, st);  // capacity read at run time

@@ -69,6 +69,15 @@ struct Dev {
   long spawn_stride;
 };
 
+// The vehicle-update counter is spread over VEH_SLOTS words, one cache line apart: every wavefront
+// adds its share once, and with one word a small launch (one tile per wave, all waves finishing
+// together) spent ~25 us serialising 1280 atomics on it (cfg1 x 1024: k_move_t 30 us -> 5 us + walk).
+constexpr int VEH_SLOTS = 256, VEH_STRIDE = 8;
+__device__ __forceinline__ void veh_add(unsigned long long *veh, unsigned long long v) {
+  const unsigned slot = (blockIdx.x * 4u + (threadIdx.x >> 6)) & (unsigned)(VEH_SLOTS - 1);
+  atomicAdd(veh + (size_t)slot * VEH_STRIDE, v);
+}
+
 __device__ __forceinline__ float np_max0(float t) { return (0.0f >= t) ? 0.0f : t; }
 __device__ __forceinline__ float pow4_cr(float q) {
   const double q2 = (double)q * (double)q;

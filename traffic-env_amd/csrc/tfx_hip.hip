@@ -258,6 +258,8 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     return gs(k_move_ts<64>);
   }
   // A/B points kept from the tuning runs
+  if (pvar == 51) return go(k_move_t<1, 3>);
+  if (pvar == 52) return go(k_move_t<2, 3>);
   if (pvar == 54) return go(k_move_t<4>);           // default caching policy (0.82 ms at cfg2)
   if (pvar == 58) return go(k_move_t<8>);
   if (pvar == 68) return go(k_move_t<8, 3>);
@@ -547,6 +549,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
+  const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {
     (void)hipFree(h->dev_tables);
     delete h;
@@ -565,7 +568,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.outb = (float2 *)(base + o_outb);
   d.leadx = (float *)(base + o_lead);
   h->n_tpairs = n_tpairs;
-  d.veh = (unsigned long long *)(base + o_misc);
+  d.veh = (unsigned long long *)(base + o_veh);
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
   d.agent_first = (const int *)(base + o_misc + 48);
@@ -575,7 +578,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   {
     const char *fd = getenv("TFX_FASTDIV");
     if (!fd || atoi(fd) != 0) {
-      unsigned long long *bad = d.veh;  // scratch word, zero at this point
+      unsigned long long *bad = (unsigned long long *)(base + o_misc);  // scratch word, zero at this point
       hipLaunchKernelGGL(k_div_selftest, dim3(h->n_cu * 8), dim3(256), 0, 0, d.two_sab, d.r_two_sab,
                          TFX_FASTDIV_A_LO, TFX_FASTDIV_A_HI, bad);
       hipLaunchKernelGGL(k_div_selftest, dim3(h->n_cu * 8), dim3(256), 0, 0, cfg->car_v0, d.r_v0,
@@ -843,15 +846,17 @@ int tfx_vehicle_updates(tfx_handle h, uint64_t *out, void *stream) {
   if (int rc = check_handle(h, false)) return rc;
   if (!out) return fail(TFX_EINVAL, "out is null");
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  std::vector<unsigned long long> slots((size_t)VEH_SLOTS * VEH_STRIDE);
+  HIPCHK(hipMemcpy(slots.data(), h->d.veh, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   unsigned long long v = 0;
-  HIPCHK(hipMemcpy(&v, h->d.veh, sizeof v, hipMemcpyDeviceToHost));
+  for (int i = 0; i < VEH_SLOTS; ++i) v += slots[(size_t)i * VEH_STRIDE];
   *out = (uint64_t)v;
   return TFX_OK;
 }
 
 int tfx_reset_counters(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, false)) return rc;
-  HIPCHK(hipMemsetAsync(h->d.veh, 0, sizeof(unsigned long long), (hipStream_t)stream));
+  HIPCHK(hipMemsetAsync(h->d.veh, 0, (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), (hipStream_t)stream));
   return TFX_OK;
 }
 

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void k_line(const Dev d, const int tidx0, const
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
-  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (lane == 0 && my_updates) veh_add(d.veh, my_updates);
 }
 
 // phase and elapsed of every intersection after the n ticks k_line just ran (the same light_next

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
-  if (lane == 0 && my_updates) atomicAdd(d.veh, my_updates);
+  if (lane == 0 && my_updates) veh_add(d.veh, my_updates);
   if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
 }
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_move(const Dev d, const int tidx) {
     }
   }
 
-  if (my_updates) atomicAdd(d.veh, my_updates);
+  if (my_updates) veh_add(d.veh, my_updates);
   if (blockIdx.x == 0 && tid == 0) *d.tickB = tick;
 }
 

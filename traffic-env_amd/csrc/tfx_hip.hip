@@ -543,8 +543,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec = off;   off = align_up(off + ER * sizeof(int4), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
-  d.trows = d.C - 2;
-  if (const char *tp = getenv("TFX_TILE_PAD")) d.trows += atoi(tp) > 0 ? atoi(tp) : 0;
+  d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 4
+#define TFX_ABI_VERSION 5
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -134,6 +134,11 @@ int tfx_bind_buffers(tfx_handle h, const tfx_buffers *b);
 /* TrafficEnv._reset (traffic_env.py:259-272).  phase_init: device int32 [E][I] (replaces
  * action_space.sample()).  detected / rewards are left stale, as in the reference. */
 int tfx_reset(tfx_handle h, const int32_t *phase_init, void *stream);
+/* The batched form's episode boundary: _reset for the envs whose byte in `mask` (device uint8 [E]) is
+ * non-zero, the others untouched; phase_init (device int32 [E][I]) is read for those envs only.  The
+ * device clock is shared by the batch and keeps running (the reference's `steps` only feeds the
+ * spawn-tick stamps, whose differences are what trip times use). */
+int tfx_reset_envs(tfx_handle h, const int32_t *phase_init, const uint8_t *mask, void *stream);
 /* Call after writing state/leading/lastcar from outside (tests, checkpoint restore): rebuilds the
  * per-road tail cache the light kernel reads. */
 int tfx_refresh(tfx_handle h, void *stream);

@@ -147,3 +147,52 @@ def test_vec_env_seeded_poisson_vs_oracle():
         live = live_mask(ld[k], lc[k], 16)
         assert np.array_equal(x[k][live], orc.x[k][live]) and np.array_equal(v[k][live], orc.v[k][live])
     assert int(eng.cars_on_roads_flat().sum()) > 30
+
+
+def test_reset_envs_resets_only_the_selected_envs():
+    """tfx_reset_envs: the episode boundary of a batched rollout.  Env by env against single-env
+    oracles: the selected envs restart from an empty network with new phases, the others continue
+    bit for bit; the batch clock keeps running."""
+    from gym_traffic.core import TfxEngine
+    E, m, n, L, C = 6, 2, 3, 90.0, 8
+    eng = TfxEngine(m, n, L, C, n_envs=E, planes=2)
+    orcs = [OracleEnv(m, n, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
+    rng = np.random.RandomState(3)
+    ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+    eng.reset(ph)
+    for k, o in enumerate(orcs):
+        o.reset(ph[k])
+    resets = 0
+    for t in range(80):
+        act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        roads = [rng.choice(eng.entrypoints, size=rng.randint(0, 3)).tolist() for _ in range(E)]
+        c = np.zeros((E, eng.n_entry), np.int32)
+        for k, rl in enumerate(roads):
+            for rd in rl:
+                c[k, eng.entry_index[int(rd)]] += 1
+        eng.set_spawns(counts=c)
+        eng.set_actions(act)
+        eng.step(1)
+        done = eng.done.cpu().numpy().astype(bool)
+        for k, o in enumerate(orcs):
+            o.steps[:] = t
+            _, _, d = o.step(act[k], [roads[k]])
+            assert bool(d[0]) == bool(done[k]), (t, k)
+        if t % 9 == 8:
+            mask = done | (rng.rand(E) < 0.3)
+            newph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+            eng.reset_envs(mask, newph)
+            for k in np.nonzero(mask)[0]:
+                orcs[k].reset(newph[k])
+                orcs[k].rewards[:] = eng.rewards[k].cpu().numpy()      # _reset leaves rewards / detected stale
+                orcs[k].obs[0, eng.r:2 * eng.r] = eng.obs[k, eng.r:2 * eng.r].cpu().numpy()
+            resets += int(mask.sum())
+            assert int(eng.done[torch.as_tensor(mask)].sum()) == 0
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        xv = eng.xv.cpu().numpy()
+        for k, o in enumerate(orcs):
+            assert np.array_equal(ld[k], o.leading[0]) and np.array_equal(lc[k], o.lastcar[0]), (t, k)
+            assert np.array_equal(eng.obs[k].cpu().numpy(), o.obs[0]), (t, k)
+            live = live_mask(ld[k], lc[k], C)
+            assert np.array_equal(xv[k][live][:, 0].view(np.int32), o.x[0][live].view(np.int32)), (t, k)
+    assert resets > 10 and eng.tick == 80

@@ -655,7 +655,17 @@ int tfx_reset(tfx_handle h, const int32_t *phase_init, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(h->d.tickA, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(h->d.tickB, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_reset, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0, st, h->d, phase_init);
+  hipLaunchKernelGGL(k_reset, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0, st, h->d, phase_init,
+                     (const uint8_t *)nullptr);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int tfx_reset_envs(tfx_handle h, const int32_t *phase_init, const uint8_t *mask, void *stream) {
+  if (int rc = check_handle(h, true)) return rc;
+  if (!phase_init || !mask) return fail(TFX_EINVAL, "phase_init and mask are required");
+  hipLaunchKernelGGL(k_reset, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0, (hipStream_t)stream,
+                     h->d, phase_init, mask);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }

@@ -6,12 +6,14 @@
 namespace tfx {
 
 // traffic_env.py:259-272
-__global__ void k_reset(const Dev d, const int *phase_init) {
+// mask == nullptr: every env; otherwise only the envs whose mask byte is non-zero (tfx_reset_envs)
+__global__ void k_reset(const Dev d, const int *phase_init, const uint8_t *mask) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x) {
     const int env = (int)(id / d.R);
     const int e = (int)(id - (long)env * d.R);
+    if (mask && !mask[env]) continue;
     if (d.layout == 0) {
       d.xv[(size_t)id * d.C + 1] = make_float2(INFINITY, 0.0f);
       if (d.w) d.w[(size_t)id * d.C + 1] = 0.0f;

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib",
 
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class TfxConfig(C.Structure):
@@ -45,6 +45,7 @@ _PROTOS = {
     "tfx_tables": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
     "tfx_bind_buffers": (C.c_int, [C.c_void_p, C.POINTER(TfxBuffers)]),
     "tfx_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tfx_reset_envs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tfx_refresh": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_set_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_spawns": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),

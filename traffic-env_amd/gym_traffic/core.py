@@ -180,6 +180,19 @@ class TfxEngine(object):
         self.tick = 0
         self.done.zero_()
 
+    def reset_envs(self, mask, phase_init):
+        """_reset for the envs selected by `mask` (bool/uint8 [E], tensor or array) only - the episode
+        boundary of a batched rollout; phase_init int [E,I] (rows of unselected envs are ignored)."""
+        m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask))
+        m = m.to(device=self.device, dtype=torch.uint8).contiguous()
+        ph = phase_init if isinstance(phase_init, torch.Tensor) else torch.as_tensor(
+            np.array(np.broadcast_to(np.asarray(phase_init, np.int32), (self.E, self.I))))
+        ph = ph.to(device=self.device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(self.device):
+            nat.check(self.lib.tfx_reset_envs(self.h, _ptr(ph), _ptr(m), self._stream()))
+        self._keep = (ph, m)
+        self.done.masked_fill_(m.bool(), 0)
+
     def refresh(self):
         """After writing xv / leading / lastcar from outside: push the ring-layout staging copy to
         the device layout (transposed handles) and rebuild the tail cache."""

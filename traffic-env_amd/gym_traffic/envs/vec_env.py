@@ -59,6 +59,16 @@ class TrafficVecEnv(object):
         eng.reset(phase_init)
         return eng.obs
 
+    def reset_done(self, done=None, phase_init=None):
+        """Start a new episode in the envs that are done (default: the `done` flags of the last step
+        or decision), leaving the others running; returns the mask that was reset."""
+        eng = self.engine
+        mask = eng.done if done is None else done
+        if phase_init is None:
+            phase_init = self._phase_rng.randint(2, size=(eng.E, eng.I)).astype(np.int32)
+        eng.reset_envs(mask, phase_init)
+        return mask
+
     def step(self, actions=None, n_ticks=1, cycle_period=None):
         """actions: int tensor [E, I] on the device (held for n_ticks, like the Repeater wrapper,
         traffic_test.py:48-49) or None with cycle_period for the on-device fixed-cycle controller.

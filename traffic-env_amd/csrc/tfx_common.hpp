@@ -128,7 +128,12 @@ __device__ __forceinline__ float div_const(float a, float c, float rc) {
 #define TFX_FASTDIV_A_LO 5e-28f
 #define TFX_FASTDIV_A_HI 4e36f
 __device__ __forceinline__ bool idm_fast_domain(float v) {
-  return (v == 0.0f) || (v >= TFX_FASTDIV_V_LO && v <= TFX_FASTDIV_V_HI);
+  // +0, or TFX_FASTDIV_V_LO <= v <= TFX_FASTDIV_V_HI, as ONE unsigned range test on the bit pattern
+  // (non-negative floats order like their bits; -0, negatives and NaNs fall outside and take the
+  // plain-division path, which is exact everywhere)
+  const unsigned b = __float_as_uint(v);
+  const unsigned lo = __float_as_uint(TFX_FASTDIV_V_LO), hi = __float_as_uint(TFX_FASTDIV_V_HI);
+  return (b == 0u) || ((b - lo) <= (hi - lo));
 }
 
 // idm_step with the two constant-divisor divisions in reciprocal form (bit-identical on the

@@ -76,10 +76,11 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
 
     // per-road running state
     float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // leader of the next car: starts as the fake one
-    int kpop = 0, n_wait = 0, n_det = 0, slot = p.ld;
+    int kpop = 0, n_wait = 0, n_det = 0;
     bool open = true, far = false;
     float tail_x = 0.0f;
-    const int lc_seg2 = (p.ld > p.lc) ? p.lc : 0;  // wrapped ring: x, not v, is tested on 1..lastcar (:210)
+    // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
+    const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
 
     // One car of this lane's road.  Runs under `if (active)`: the EXEC mask keeps the running state
     // of lanes whose road is shorter than the tile's longest untouched.
@@ -115,17 +116,17 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       xprev = x;  // OLD state leads the next car (Jacobi)
       vprev = v;
       llv = d.car_l;
-      slot = (slot + 1 >= C) ? 1 : slot + 1;  // the reference's ring slot of this car
       const bool pop = open && (xn > d.length) && !(d.dbg & 128);  // the while loop of :123 (128: ablation)
       open = pop;
-      far = far || (pop && ((xn - d.length) > d.length));
-      if (pop) ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-      else if (BATCH) {
+      if (pop) {
+        ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+        far = far || ((xn - d.length) > d.length);
+      } else if (BATCH) {
         outv[ucur] = make_float2(xn, vn);
         outrow[ucur] = k - kpop;
       } else st2(&col[(size_t)(k - kpop) * 64], xn, vn);
       kpop += pop ? 1 : 0;
-      const float wq = (slot <= lc_seg2) ? xn : vn;
+      const float wq = (k >= kq) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
       n_det += (xn > d.near_end) ? 1 : 0;
       tail_x = xn;

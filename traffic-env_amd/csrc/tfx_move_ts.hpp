@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
     unsigned long long popmask = 0ull;
     float tail_x = 0.0f;
     bool has_tail = false;
-    const int lc_seg2 = (p.ld > p.lc) ? p.lc : 0;  // wrapped ring: x, not v, is tested on 1..lastcar (:210)
+    // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
+    const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
 #pragma unroll
     for (int u = 0; u < KS; ++u) {
       const int k = k0 + u;
@@ -125,13 +126,12 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
         lx = x;  // OLD state leads the next car (Jacobi)
         lv = v;
         ll = d.car_l;
-        const int slot = ring_adv(p.ld, k + 1, C);
         const bool pop = open && (xn > d.length);
         open = pop;
         if (pop) popmask |= 1ull << u;
         kpop += pop ? 1 : 0;
         far = far || (pop && ((xn - d.length) > d.length));
-        const float wq = (slot <= lc_seg2) ? xn : vn;
+        const float wq = (k >= kq) ? xn : vn;
         n_wait += (wq < d.thresh) ? 1 : 0;
         n_det += (xn > d.near_end) ? 1 : 0;
         if (k == n_tot - 1) {

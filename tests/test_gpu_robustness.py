@@ -109,3 +109,45 @@ def test_cabi_argument_errors_on_device():
     assert lib.tfx_create(C.byref(cfg), C.byref(h2)) == 0
     assert lib.tfx_step(h2, 1, None) == -2                # buffers not bound yet
     assert lib.tfx_destroy(h2) == 0
+
+
+def test_fuzz_small_configurations_vs_oracle():
+    """Thirty random small configurations - grid shape, capacity, road length, rate, learn_switch,
+    entry sides, batch size, layout, arrival density - each stepped free-running for 40 ticks in
+    uneven multi-tick calls with per-tick buffers: bit-equal to the oracle at the end of every call."""
+    from gym_traffic.core import TfxEngine
+    from oracle.oracle import OracleEnv
+    from test_gpu_parity import assert_same_state, counts
+    rng = np.random.RandomState(20251003)
+    for trial in range(30):
+        m, n = int(rng.randint(1, 5)), int(rng.randint(1, 5))
+        C = int(rng.choice([3, 4, 6, 9, 10, 17, 20, 33, 34, 66]))
+        L = float(rng.choice([30.0, 75.0, 140.0, 250.0]))
+        rate = float(rng.choice([0.25, 0.5, 1.0]))
+        ls = bool(rng.randint(2))
+        spec = int(rng.choice([0, 0, 0b0001, 0b1010, 0b1110]))
+        E = int(rng.choice([1, 2, 5, 70]))
+        layout = str(rng.choice(["ring", "transposed"]))
+        planes = 2 if layout == "transposed" else int(rng.choice([2, 3]))
+        eng = TfxEngine(m, n, L, C, n_envs=E, rate=rate, learn_switch=ls, entry_spec=spec, planes=planes,
+                        layout=layout)
+        orc = OracleEnv(m, n, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, rate=rate, learn_switch=ls)
+        ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        eng.reset(ph)
+        orc.reset(ph)
+        dens = rng.choice([0.1, 0.5, 1.5])
+        t = 0
+        while t < 40:
+            k = int(min(40 - t, rng.choice([1, 1, 2, 3, 7])))
+            acts = rng.randint(2, size=(k, E, eng.I)).astype(np.int32)
+            roads = [[(rng.choice(eng.entrypoints, size=rng.poisson(dens)).tolist() if eng.n_entry else [])
+                      for _ in range(E)] for _ in range(k)]
+            eng.set_actions(acts, per_tick=True)
+            eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+            eng.step(k)
+            done = np.zeros(E, bool)
+            for j in range(k):
+                done |= orc.step(acts[j], roads[j])[2].astype(bool)
+            assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (trial, t)
+            t += k
+            assert_same_state(eng, orc, "trial %d (%dx%d C=%d E=%d %s) tick %d" % (trial, m, n, C, E, layout, t))

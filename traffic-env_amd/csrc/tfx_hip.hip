@@ -163,9 +163,23 @@ void build_slots(tfx_handle_s *h) {
       for (size_t q = 0; q < lines[li].size(); ++q)
         h->h_slot_road[(li / per_tile) * 64 + (li % per_tile) * longest + q] = lines[li][q];
   } else {
+    // Roads of a kind behave alike - entry roads queue the arrivals, exit roads only drain - and a
+    // wavefront walks its tile as far as the tile's LONGEST road, so kinds are not mixed: interior
+    // train roads in id order (runs of consecutive ids: the per-road words still coalesce), then the
+    // entry roads, then the exit roads.  At cfg2 that is 15 + 1 + 1 tiles instead of ten tiles that
+    // each carry a few long entry roads (TFX_KINDS=0: plain id order).
+    const char *kv = getenv("TFX_KINDS");
+    std::vector<int> order;
+    if (!(kv && atoi(kv) == 0)) {
+      for (int e = 0; e < r; ++e) if (h->h_pred[e] >= 0) order.push_back(e);
+      for (int e = 0; e < r; ++e) if (h->h_pred[e] < 0) order.push_back(e);
+      for (int e = r; e < R; ++e) order.push_back(e);
+    } else {
+      for (int e = 0; e < R; ++e) order.push_back(e);
+    }
     h->tiles_per_env = (R + 63) / 64;
     h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
-    for (int e = 0; e < R; ++e) h->h_slot_road[e] = e;
+    for (int s = 0; s < R; ++s) h->h_slot_road[s] = order[s];
   }
   h->h_road_slot.assign(R, -1);
   for (size_t s = 0; s < h->h_slot_road.size(); ++s)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 5
+#define TFX_ABI_VERSION 6
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -95,10 +95,11 @@ typedef struct tfx_config {
   int32_t env_id_offset; /* global id of env 0 of this handle (env-sharded multi-GPU runs): the
                             on-device controllers use env + offset, so results do not depend on the
                             sharding */
-  int32_t layout;        /* 0: xv is the ring layout above; 1: transposed layout (planes = 2 only) - xv is
-                            T[tile][k][64][2]: the k-th car behind the fake leader of road (64*tile + j)
-                            at T[tile][k][j]; tfx_xv_pairs gives its size, tfx_export_ring /
-                            tfx_import_ring convert to and from the ring layout */
+  int32_t layout;        /* 0: xv is the ring layout above; 1: transposed layout - xv is T[tile][k][64][2]:
+                            the k-th car behind the fake leader of the road in storage slot (64*tile + j)
+                            at T[tile][k][j] (with planes = 3, w is T[tile][k][64] likewise);
+                            tfx_xv_pairs gives the size, tfx_export_ring / tfx_import_ring convert to
+                            and from the ring layout */
 } tfx_config;
 
 typedef struct tfx_buffers {
@@ -190,13 +191,15 @@ int tfx_reset_counters(tfx_handle h, void *stream);
  * tfx_profile_read waits for them and returns (and clears) the summed durations. 0 disables. */
 int tfx_profile(tfx_handle h, int32_t max_ticks);
 int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t *n_ticks);
-/* (x, v) pairs the caller's xv buffer must hold for this handle's layout */
+/* (x, v) pairs the caller's xv buffer must hold for this handle's layout (and, with planes = 3 on the
+ * transposed layout, floats its w buffer must hold) */
 int tfx_xv_pairs(tfx_handle h, int64_t *pairs);
-/* Transposed-layout handles: copy the cars to / from a ring-layout array float32 [E][R][C][2] (device
- * pointer), the fake leader's x in slot `leading` as the reference keeps it.  After an import call
+/* Transposed-layout handles: copy the cars to / from ring-layout arrays (device pointers): ring_xv
+ * float32 [E][R][C][2] with the fake leader's x in slot `leading` as the reference keeps it, ring_w
+ * float32 [E][R][C] (spawn ticks; may be NULL, ignored unless planes = 3).  After an import call
  * tfx_refresh. */
-int tfx_export_ring(tfx_handle h, float *ring_xv, void *stream);
-int tfx_import_ring(tfx_handle h, const float *ring_xv, void *stream);
+int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, void *stream);
+int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, void *stream);
 
 /* Two of the IDM's three divisions have a constant divisor (2*sqrt(a*b) and v0).  At tfx_create the
  * library checks on the device, exhaustively over the admitted numerator range, that the

@@ -22,6 +22,18 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+# every test of this module runs on both car layouts (TFX_TEST_LAYOUT=ring|transposed restricts)
+LAYOUTS = [os.environ["TFX_TEST_LAYOUT"]] if os.environ.get("TFX_TEST_LAYOUT") else ["ring", "transposed"]
+_LAYOUT = ["ring"]
+
+
+@pytest.fixture(params=LAYOUTS, autouse=True)
+def car_layout(request):
+    _LAYOUT[0] = request.param
+    yield request.param
+    _LAYOUT[0] = "ring"
+
+
 def engine_for(g_or_cfg, n_envs=1, **kw):
     from gym_traffic.core import TfxEngine
     if isinstance(g_or_cfg, dict):
@@ -33,10 +45,9 @@ def engine_for(g_or_cfg, n_envs=1, **kw):
                  entry_spec=0b1110 if sc["entry"] == "one" else 0)
     c = dict(c)
     c.update(kw)
-    # TFX_TEST_LAYOUT=transposed runs this whole module on the position-major layout (it carries no
-    # spawn-tick plane, so validate-mode cases keep the ring layout)
-    planes = 2 if (os.environ.get("TFX_TEST_LAYOUT") == "transposed" and not c.get("validate")) else 3
-    return TfxEngine(n_envs=n_envs, planes=planes, **c)
+    # ring: all three planes; transposed: the spawn-tick plane only where validate mode needs it
+    planes = 3 if (_LAYOUT[0] == "ring" or c.get("validate")) else 2
+    return TfxEngine(n_envs=n_envs, planes=planes, layout=_LAYOUT[0], **c)
 
 
 def oracle_like(eng, **kw):

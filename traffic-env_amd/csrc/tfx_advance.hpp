@@ -198,9 +198,10 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
           const int rxx = d.rec[idx].x;
           int ps = rec_head(rxx);
           for (int j = 0; j < rec_kpop(rxx); ++j) {
+            // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed)
+            const float cw = !d.w ? 0.0f : (TL ? d.outw[tpos(d, idx, j)] : d.w[(size_t)idx * d.C + ps]);
             if (d.trip_times && t < d.trip_cap)
-              d.trip_times[(size_t)env * d.trip_cap + t] =
-                  ((float)tick - (d.w ? d.w[(size_t)idx * d.C + ps] : 0.0f)) / 2.0f;
+              d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
             ++t;
             ps = wrap1(ps + 1, d.C);
           }

@@ -38,6 +38,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
         if (pos != ld_seen) {
           const float xv = (start < xc) ? start : xc;
           d.xv[ecol + (size_t)m * 64] = make_float2(xv, car.y);
+          if (d.w) d.w[ecol + (size_t)m * 64] = d.outw[pcol + (size_t)j * 64];
           ++m;
           lc = pos;
           tail_x = xv;
@@ -78,7 +79,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     for (int e = 0; e < d.r; ++e) ob[e] -= rec_kpop(d.rec[env * d.R + e].x);
 
   // add_car (:97-114) into road nr; `done_upto` = roads whose own pops have been processed
-  auto push = [&](int nr, float2 car, int done_upto) {
+  auto push = [&](int nr, float2 car, float cw, int done_upto) {
     const int idn = env * d.R + nr;
     const int4 rn = d.rec[idn];
     const int lcn = d.lastcar[idn], ldn = d.leading[idn];
@@ -92,10 +93,20 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     }
     if (pos != ldn) {
       d.xv[tpos(d, idn, phys)] = make_float2((start < car.x) ? start : car.x, car.y);
+      if (d.w) d.w[tpos(d, idn, phys)] = cw;
       d.lastcar[idn] = pos;
     } else {
       if (nr < d.r) rew[nr % d.I] -= d.ovf_pen;
       overflowed = 1;
+    }
+  };
+
+  // advance_hack :153-154: a car leaving the map records (tick - spawn tick) / 2
+  auto trip = [&](float cw) {
+    if (d.validate && d.n_trips) {
+      const int t = d.n_trips[env];
+      if (d.trip_times && t < d.trip_cap) d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
+      d.n_trips[env] = t + 1;
     }
   };
 
@@ -106,12 +117,15 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int k_e = rec_kpop(d.rec[id].x);
     // the road's own popped cars, in order
     for (int j = 0; j < k_e; ++j) {
+      const float cw = d.w ? d.outw[tpos(d, id, j)] : 0.0f;
       if (nr >= 0) {
         ob[e] += 1;
         d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
         float2 car = d.outb[tpos(d, id, j)];
         car.x -= d.length;
-        push(nr, car, e - 1);
+        push(nr, car, cw, e - 1);
+      } else {
+        trip(cw);
       }
       ld = wrap1(ld + 1, C);
       d.leading[id] = ld;
@@ -119,15 +133,21 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     // cars pushed onto an (otherwise emptied) road that are themselves beyond its end
     while (ld != d.lastcar[id] && d.xv[tpos(d, id, 0)].x > d.length) {
       float2 car = d.xv[tpos(d, id, 0)];
+      const float cw = d.w ? d.w[tpos(d, id, 0)] : 0.0f;
       const int phys = ring_count(ld, d.lastcar[id], C);
-      for (int q = 1; q < phys; ++q) d.xv[tpos(d, id, q - 1)] = d.xv[tpos(d, id, q)];
+      for (int q = 1; q < phys; ++q) {
+        d.xv[tpos(d, id, q - 1)] = d.xv[tpos(d, id, q)];
+        if (d.w) d.w[tpos(d, id, q - 1)] = d.w[tpos(d, id, q)];
+      }
       ld = wrap1(ld + 1, C);
       d.leading[id] = ld;
       if (nr >= 0) {
         ob[e] += 1;
         d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
         car.x -= d.length;
-        push(nr, car, e);
+        push(nr, car, cw, e);
+      } else {
+        trip(cw);
       }
     }
   }

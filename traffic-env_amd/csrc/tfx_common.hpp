@@ -54,6 +54,7 @@ struct Dev {
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this
   // tick wait in its outbox column; the fake leader's x has no slot of its own and lives in leadx
   float2 *outb;
+  float *outw;  // outbox of the spawn-tick plane (transposed layout with planes = 3); w itself is T-shaped
   float *leadx;
   int layout;
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)

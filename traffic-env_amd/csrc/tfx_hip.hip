@@ -266,11 +266,18 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
       return (int)TFX_OK;
     };
     const int cap = h->d.C - 2;
+    if (h->d.w) {
+      if (cap <= 32) return gs(k_move_ts<8, true>);
+      if (cap <= 64) return gs(k_move_ts<16, true>);
+      if (cap <= 128) return gs(k_move_ts<32, true>);
+      return gs(k_move_ts<64, true>);
+    }
     if (cap <= 32) return gs(k_move_ts<8>);
     if (cap <= 64) return gs(k_move_ts<16>);
     if (cap <= 128) return gs(k_move_ts<32>);
     return gs(k_move_ts<64>);
   }
+  if (h->d.w) return go(k_move_t<4, 3, false, true>);  // validate mode: the spawn-tick plane travels along
   // A/B points kept from the tuning runs
   if (pvar == 51) return go(k_move_t<1, 3>);
   if (pvar == 52) return go(k_move_t<2, 3>);
@@ -476,7 +483,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (cfg->planes != 2 && cfg->planes != 3) return fail(TFX_EINVAL, "planes must be 2 (x,v) or 3 (x,v,w)");
   if (cfg->validate && cfg->planes != 3) return fail(TFX_EINVAL, "validate mode needs planes = 3 (spawn tick w)");
   if (cfg->layout != 0 && cfg->layout != 1) return fail(TFX_EINVAL, "layout must be 0 (ring) or 1 (transposed)");
-  if (cfg->layout == 1 && cfg->planes != 2) return fail(TFX_EINVAL, "the transposed layout carries (x, v) only: planes must be 2");
   if (cfg->car_delta != 4.0f) return fail(TFX_EINVAL, "only delta = 4 (the reference's archetype) is supported");
   if (!(cfg->length > 0.0f) || !(cfg->rate > 0.0f)) return fail(TFX_EINVAL, "length and rate must be > 0");
   int ndev = 0;
@@ -560,6 +566,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
+  const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_tpairs * sizeof(float) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
@@ -579,6 +586,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
   d.outb = (float2 *)(base + o_outb);
+  d.outw = (float *)(base + o_outw);
   d.leadx = (float *)(base + o_lead);
   h->n_tpairs = n_tpairs;
   d.veh = (unsigned long long *)(base + o_veh);
@@ -925,22 +933,22 @@ int tfx_xv_pairs(tfx_handle h, int64_t *pairs) {
   return TFX_OK;
 }
 
-int tfx_export_ring(tfx_handle h, float *ring_xv, void *stream) {
+int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
   if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
   hipLaunchKernelGGL(k_export_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
-                     (hipStream_t)stream, h->d, reinterpret_cast<float2 *>(ring_xv));
+                     (hipStream_t)stream, h->d, reinterpret_cast<float2 *>(ring_xv), ring_w);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
-int tfx_import_ring(tfx_handle h, const float *ring_xv, void *stream) {
+int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
   if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
   hipLaunchKernelGGL(k_import_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
-                     (hipStream_t)stream, h->d, reinterpret_cast<const float2 *>(ring_xv));
+                     (hipStream_t)stream, h->d, reinterpret_cast<const float2 *>(ring_xv), ring_w);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }

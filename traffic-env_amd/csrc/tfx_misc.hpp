@@ -58,7 +58,7 @@ __global__ void k_refresh(const Dev d) {
 
 // transposed layout <-> the reference's ring layout ([E][R][C] (x, v) by ring slot, the fake
 // leader's x in slot `leading`): what tfx_export_ring / tfx_import_ring run
-__global__ void k_export_ring(const Dev d, float2 *ring) {
+__global__ void k_export_ring(const Dev d, float2 *ring, float *ringw) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x) {
@@ -69,12 +69,13 @@ __global__ void k_export_ring(const Dev d, float2 *ring) {
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
       row[slot] = d.xv[tpos(d, (int)id, k)];
+      if (ringw && d.w) ringw[(size_t)id * d.C + slot] = d.w[tpos(d, (int)id, k)];
     }
     row[ld].x = d.leadx[id];
   }
 }
 
-__global__ void k_import_ring(const Dev d, const float2 *ring) {
+__global__ void k_import_ring(const Dev d, const float2 *ring, const float *ringw) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x) {
@@ -85,6 +86,7 @@ __global__ void k_import_ring(const Dev d, const float2 *ring) {
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
       d.xv[tpos(d, (int)id, k)] = row[slot];
+      if (ringw && d.w) d.w[tpos(d, (int)id, k)] = ringw[(size_t)id * d.C + slot];
     }
     d.leadx[id] = row[ld].x;
   }

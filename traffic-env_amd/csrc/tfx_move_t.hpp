@@ -39,7 +39,8 @@ __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
 // back, the group is computed, its P stores are issued back to back - instead of one load and one
 // store per row (longer same-direction bursts at the memory side; tools/copy_probe.hip measures
 // 5.8 TB/s for 4-row and 6.1 TB/s for 8-row groups on this access shape)
-template <int P, int NT = 0, bool BATCH = false>
+// W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157)
+template <int P, int NT = 0, bool BATCH = false, bool W = false>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
 
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;     // T[k] of this road = col[k * 64]
     float2 *ocol = d.outb + ((size_t)tile * d.trows) * 64 + lane;  // outbox column of this road
+    float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
+    float *owcol = W ? d.outw + ((size_t)tile * d.trows) * 64 + lane : nullptr;
 
     // longest road of the tile (wave-uniform loop bound)
     int kmax = n_old;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     float2 outv[P];  // BATCH: survivors of the current group and their destination rows (-1: none)
     int outrow[P];
     int ucur = 0;
-    auto step = [&](int k, float x, float v) {
+    auto step = [&](int k, float x, float v, float wv) {
       float xn, vn;
       const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
       if (d.dbg & 64) {  // timing ablation: no arithmetic (results are wrong)
@@ -120,11 +123,16 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       open = pop;
       if (pop) {
         ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+        if (W) owcol[(size_t)kpop * 64] = wv;
         far = far || ((xn - d.length) > d.length);
       } else if (BATCH) {
         outv[ucur] = make_float2(xn, vn);
         outrow[ucur] = k - kpop;
-      } else st2(&col[(size_t)(k - kpop) * 64], xn, vn);
+        if (W) wcol[(size_t)(k - kpop) * 64] = wv;
+      } else {
+        st2(&col[(size_t)(k - kpop) * 64], xn, vn);
+        if (W) wcol[(size_t)(k - kpop) * 64] = wv;
+      }
       kpop += pop ? 1 : 0;
       const float wq = (k >= kq) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
@@ -134,26 +142,34 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
 
     // ---- cars in memory: rows 0 .. kmax-1, P rows in flight ------------------------------------
     float2 pf[P];
+    float pfw[P];
 #pragma unroll
-    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? ld2(&col[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+    for (int u = 0; u < P; ++u) {
+      pf[u] = (u < n_old) ? ld2(&col[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+      pfw[u] = (W && u < n_old) ? wcol[(size_t)u * 64] : 0.0f;
+    }
     if (BATCH) {
       for (int k0 = 0; k0 < kmax; k0 += P) {
         float2 cur[P];
+        float curw[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
           cur[u] = pf[u];
+          curw[u] = pfw[u];
           outrow[u] = -1;
         }
         if (k0 + P < kmax) {
 #pragma unroll
-          for (int u = 0; u < P; ++u)
+          for (int u = 0; u < P; ++u) {
             pf[u] = (k0 + P + u < n_old) ? ld2(&col[(size_t)(k0 + P + u) * 64]) : make_float2(0.0f, 0.0f);
+            pfw[u] = (W && k0 + P + u < n_old) ? wcol[(size_t)(k0 + P + u) * 64] : 0.0f;
+          }
         }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
           const int k = k0 + u;
           ucur = u;
-          if (k < n_old) step(k, cur[u].x, cur[u].y);
+          if (k < n_old) step(k, cur[u].x, cur[u].y, curw[u]);
         }
 #pragma unroll
         for (int u = 0; u < P; ++u)
@@ -166,8 +182,12 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
           const int k = k0 + u;
           if (k < kmax) {
             const float2 cur = pf[u];
-            if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&col[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
-            if (k < n_old) step(k, cur.x, cur.y);
+            const float curw = pfw[u];
+            if (k + P < kmax) {
+              pf[u] = (k + P < n_old) ? ld2(&col[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+              pfw[u] = (W && k + P < n_old) ? wcol[(size_t)(k + P) * 64] : 0.0f;
+            }
+            if (k < n_old) step(k, cur.x, cur.y, curw);
           }
         }
       }
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       smax = __builtin_amdgcn_readfirstlane(smax);
       for (int s = 0; s < smax; ++s) {
         if (BATCH) outrow[0] = -1;
-        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v);
+        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick);  // w = spawn tick
         if (BATCH && outrow[0] >= 0) st2(&col[(size_t)outrow[0] * 64], outv[0].x, outv[0].y);
       }
     }

@@ -19,7 +19,7 @@
 
 namespace tfx {
 
-template <int KS>  // cars per segment held in registers: C - 2 <= 4 * KS
+template <int KS, bool W = false>  // KS cars per segment held in registers: C - 2 <= 4 * KS; W: spawn-tick plane
 __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
   constexpr int S = 4;
   __shared__ int s_wait[S][64], s_det[S][64], s_kpop[64];
@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
     const int n_tot = run ? p.n_tot : 0;
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
     float2 *ocol = d.outb + ((size_t)tile * d.trows) * 64 + lane;
+    float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
+    float *owcol = W ? d.outw + ((size_t)tile * d.trows) * 64 + lane : nullptr;
 
     int kmax = n_tot;
 #pragma unroll
@@ -97,15 +99,17 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
     }
     const int kpop0 = kpop;
 
-    float cx[KS], cv[KS];
+    float cx[KS], cv[KS], cw[W ? KS : 1];
 #pragma unroll
     for (int u = 0; u < KS; ++u) {
       const int k = k0 + u;
       cx[u] = cv[u] = 0.0f;
+      if (W) cw[u] = 0.0f;
       if (k < k1 && k < n_tot) {
         const float2 c = old_car(k);
         cx[u] = c.x;
         cv[u] = c.y;
+        if (W) cw[u] = (k < n_old) ? wcol[(size_t)k * 64] : (float)tick;  // spawned this tick: w = tick
       }
     }
     int n_wait = 0, n_det = 0;
@@ -150,9 +154,11 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
         if (k < k1 && k < n_tot) {
           if ((popmask >> u) & 1ull) {
             ocol[(size_t)kp * 64] = make_float2(cx[u], cv[u]);
+            if (W) owcol[(size_t)kp * 64] = cw[u];
             ++kp;
           } else {
             col[(size_t)(k - kp) * 64] = make_float2(cx[u], cv[u]);
+            if (W) wcol[(size_t)(k - kp) * 64] = cw[u];
           }
         }
       }

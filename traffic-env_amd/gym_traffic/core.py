@@ -67,7 +67,7 @@ class TfxEngine(object):
         cfg.entry_spec = int(entry_spec)
         cfg.env_id_offset = int(env_id_offset)
         if layout is None:
-            layout = os.environ.get("TFX_LAYOUT") or ("transposed" if self.P == 2 else "ring")
+            layout = os.environ.get("TFX_LAYOUT") or "transposed"
         if layout not in ("ring", "transposed"):
             raise ValueError("layout must be 'ring' or 'transposed'")
         self.layout = layout
@@ -102,7 +102,11 @@ class TfxEngine(object):
             self._t = torch.zeros((int(pairs.value), 2), dtype=torch.float32, device=dev)
         else:
             self._t = None
-        self.w = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
+        # spawn ticks (validate mode): ring-shaped array (the live one on the ring layout, a staging copy
+        # on the transposed layout, whose own w buffer is T-shaped like the cars)
+        self._ringw = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
+        self._tw = (torch.zeros((self._t.shape[0],), dtype=torch.float32, device=dev)
+                    if (P == 3 and self._t is not None) else None)
         self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.obs = torch.zeros((E, self.obs_len), dtype=torch.int32, device=dev)
@@ -116,7 +120,8 @@ class TfxEngine(object):
         self.n_trips = torch.zeros((E,), dtype=torch.int32, device=dev) if validate else None
         self._cars = torch.zeros((E, R), dtype=torch.int32, device=dev)
         b = nat.TfxBuffers()
-        b.xv, b.w = _ptr(self._t if self._t is not None else self._ring), _ptr(self.w)
+        b.xv = _ptr(self._t if self._t is not None else self._ring)
+        b.w = _ptr(self._tw if self._tw is not None else self._ringw)
         b.leading, b.lastcar = _ptr(self.leading), _ptr(self.lastcar)
         b.obs, b.rewards, b.waiting = _ptr(self.obs), _ptr(self.rewards), _ptr(self.waiting)
         b.passed_dst, b.done_tick = _ptr(self.passed_dst), _ptr(self.done_tick)
@@ -140,7 +145,7 @@ class TfxEngine(object):
     def _export(self):
         if self._t is not None:
             with torch.cuda.device(self.device):
-                nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), self._stream()))
+                nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
 
     @property
     def xv(self):
@@ -148,6 +153,14 @@ class TfxEngine(object):
         staging copy brought up to date by this access; write to it, then call refresh()."""
         self._export()
         return self._ring
+
+    @property
+    def w(self):
+        """[E,R,C] spawn tick by ring slot (None unless planes == 3); same staging rule as `xv`."""
+        if self._ringw is None:
+            return None
+        self._export()
+        return self._ringw
 
     @property
     def x(self):
@@ -198,7 +211,7 @@ class TfxEngine(object):
         the device layout (transposed handles) and rebuild the tail cache."""
         with torch.cuda.device(self.device):
             if self._t is not None:
-                nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), self._stream()))
+                nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 
     def set_poisson(self, cars_per_tick, seed=0):
@@ -391,8 +404,8 @@ class TfxEngine(object):
         """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
         self._ring[..., 0].copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
         self._ring[..., 1].copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
-        if self.w is not None and w is not None:
-            self.w.copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
+        if self._ringw is not None and w is not None:
+            self._ringw.copy_(torch.as_tensor(np.asarray(w, np.float32)).to(self.device))
         self.leading.copy_(torch.as_tensor(np.asarray(leading, np.int32)).to(self.device))
         self.lastcar.copy_(torch.as_tensor(np.asarray(lastcar, np.int32)).to(self.device))
         self.refresh()

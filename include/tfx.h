@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 6
+#define TFX_ABI_VERSION 7
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -214,6 +214,25 @@ int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_
  * asked for >= 2 ticks, the spawn rule and the controller do not depend on the cars (no on-device
  * Poisson / greedy), and validate mode is off; results are bit-identical either way. */
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
+
+/* Host-side replay of the reference's seeded arrival generators for many envs (no GPU involved): one
+ * stream per env holds a legacy numpy RandomState's MT19937 state (`RandomState.get_state()[1:3]`)
+ * plus the generator's own state - `gap`: whole ticks left before the next Poisson car (-1 = draw a
+ * new gap), `tick`: the regular generator's tick counter.  tfx_arrivals_replay advances every stream
+ * by n_ticks exactly as traffic_env.py:160-176 + :274-283 would (poisson != 0: round(Exp(mean_gap))
+ * empty ticks between cars; else `burst` cars every `every` ticks), drawing each car's entry road
+ * with rand.choice over n_choices entry points.  counts int32 [n_ticks][n_streams][n_columns] receives
+ * the cars per entry road (choice c -> column column_of_choice[c]), made int32 [n_ticks][n_streams]
+ * (may be NULL) the cars created. */
+typedef struct tfx_arrival_stream {
+  uint32_t mt[624];
+  int32_t pos;
+  int32_t gap;
+  int64_t tick;
+} tfx_arrival_stream;
+int tfx_arrivals_replay(tfx_arrival_stream *streams, int32_t n_streams, int32_t n_ticks, int32_t poisson,
+                        double mean_gap, int32_t every, int32_t burst, int32_t n_choices,
+                        const int32_t *column_of_choice, int32_t n_columns, int32_t *counts, int32_t *made);
 
 #ifdef __cplusplus
 }

@@ -205,3 +205,32 @@ def test_spawn_schedule_shortcuts_consume_the_stream_like_the_literal_calls():
             assert gap_a == gap_b and road_a == road_b
         sa, sb = a.get_state(), b.get_state()
         assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+
+
+def test_arrival_streams_in_c_equal_the_python_replay_and_numpy():
+    """tfx_arrivals_replay (csrc/tfx_arrivals.cpp) against SpawnSchedule - which itself equals the
+    reference's generators call for call - for both generators, many seeds, several rates: same cars
+    on the same entry roads in the same ticks, and the MT19937 stream left in the same state."""
+    from gym_traffic.spawner import ArrivalStreams, SpawnSchedule, counts_from_roads
+    ent = np.array([0, 4, 8, 12, 19, 23, 27, 31, 32, 33, 34, 35, 60, 61, 62, 63], np.int32)
+    col = {int(rd): j for j, rd in enumerate(ent)}
+    for poisson in (True, False):
+        for cpt in (0.07, 0.48, 1.0, 3.84):
+            seeds = list(range(11, 11 + 9))
+            c_side = ArrivalStreams(seeds, poisson, ent, col, len(ent), cpt)
+            py = [SpawnSchedule(np.random.RandomState(s), poisson, ent, lambda: (cpt, 1.0)) for s in seeds]
+            total = 0
+            for chunk in (1, 7, 40, 3):
+                counts, made = c_side.next_ticks(chunk)
+                counts, made = counts.copy(), made.copy()
+                for t in range(chunk):
+                    for k, sch in enumerate(py):
+                        roads = sch.next_tick()
+                        want = counts_from_roads(roads, col, len(ent))
+                        assert np.array_equal(counts[t, k], want), (poisson, cpt, k, t)
+                        assert made[t, k] == len(roads)
+                        total += len(roads)
+            assert total > 0
+            for k, sch in enumerate(py):
+                a, b = sch.rand.get_state(), c_side.random_state(k).get_state()
+                assert np.array_equal(a[1], b[1]) and a[2] == b[2], (poisson, cpt, k)

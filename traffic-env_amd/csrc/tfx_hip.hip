@@ -977,3 +977,6 @@ int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_
 }
 
 }  // extern "C"
+
+// host-only: replay of the reference's seeded arrival generators for many envs
+#include "tfx_arrivals.cpp"

@@ -12,7 +12,7 @@ import torch
 
 from gym_traffic.core import TfxEngine
 from gym_traffic.envs.roadgraph import GridRoad
-from gym_traffic.spawner import SpawnSchedule, counts_from_roads
+from gym_traffic.spawner import ArrivalStreams
 
 
 class TrafficVecEnv(object):
@@ -34,11 +34,10 @@ class TrafficVecEnv(object):
         if spawn in ('poisson', 'regular'):
             # env k of this shard is global env (env_id_offset + k): its stream does not depend on
             # how the envs are sharded over GPUs
-            self._sched = [SpawnSchedule(np.random.RandomState(seed + self.env_id_offset + k),
-                                         spawn == 'poisson', self.graph.entrypoints,
-                                         lambda: (self.cars_per_sec, self.rate))
-                           for k in range(self.num_envs)]
-            self._counts = np.zeros((self.num_envs, max(1, eng.n_entry)), np.int32)
+            # (replayed in C for all envs at once: reference-identical arrivals at any batch size)
+            self._arrivals = ArrivalStreams([seed + self.env_id_offset + k for k in range(self.num_envs)],
+                                            spawn == 'poisson', self.graph.entrypoints, eng.entry_index,
+                                            max(1, eng.n_entry), self.cars_per_sec * self.rate)
         elif spawn == 'periodic':
             eng.set_spawns(period=spawn_period)
         elif spawn in (None, 'none'):
@@ -79,13 +78,9 @@ class TrafficVecEnv(object):
         elif actions is not None:
             eng.set_actions(actions)
         if self.spawn in ('poisson', 'regular'):
-            for _ in range(int(n_ticks)):
-                for k, s in enumerate(self._sched):
-                    counts_from_roads(s.next_tick(), eng.entry_index, eng.n_entry, out=self._counts[k])
-                eng.set_spawns(counts=self._counts)
-                eng.step(1)
-        else:
-            eng.step(int(n_ticks))
+            counts, _ = self._arrivals.next_ticks(int(n_ticks))
+            eng.set_spawns(counts=counts, per_tick=True)
+        eng.step(int(n_ticks))
         return eng.obs, eng.rewards, eng.done
 
     def agent_step(self, actions=None, n_ticks=10, remi=True, cycle_period=None):
@@ -100,12 +95,8 @@ class TrafficVecEnv(object):
         elif actions is not None:
             eng.set_actions(actions)
         if self.spawn in ('poisson', 'regular'):
-            if getattr(self, '_tick_counts', None) is None or self._tick_counts.shape[0] != n:
-                self._tick_counts = np.zeros((n,) + self._counts.shape, np.int32)
-            for t in range(n):
-                for k, s in enumerate(self._sched):
-                    counts_from_roads(s.next_tick(), eng.entry_index, eng.n_entry, out=self._tick_counts[t, k])
-            eng.set_spawns(counts=self._tick_counts, per_tick=True)
+            counts, _ = self._arrivals.next_ticks(n)
+            eng.set_spawns(counts=counts, per_tick=True)
         return eng.agent_step(n, remi=remi)
 
     def remi_reward(self):

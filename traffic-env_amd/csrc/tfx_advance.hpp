@@ -29,11 +29,9 @@ __device__ __forceinline__ int advance_road(const Dev &d, int env, int e, int ti
   const int C = d.C;
   const int id = env * d.R + e;
   const int ld = d.leading[id];
-  const int lc0 = d.lastcar[id];
-  int lc = lc0;
+  int lc = d.lastcar[id];
   const int4 rc = d.rec[id];
   const int k_e = rec_kpop(rc.x);
-  const float tail0 = d.tailx[id];  // e's tail before this tick's move: what p's fake leader saw
   float tail_x = __int_as_float(rc.z);
   const int ld_post = ring_adv(ld, k_e, C);
   float2 *rx = d.xv + (size_t)id * C;
@@ -65,15 +63,11 @@ __device__ __forceinline__ int advance_road(const Dev &d, int env, int e, int ti
         if (j + 1 < k_p) ps = wrap1(ps + 1, C);
       }
       d.lastcar[id] = lc;
-      // p's new leader slot (its last popped car) gets p's fake-leader x (:133), recomputed the
-      // way update_lights (:81-94) set it this tick: from p's light and e's tail before the move
-      int ph_new, el_new;
-      const int dirp = p / d.I;
-      light_update(d, env, p - dirp * d.I, tick, tidx, ph_new, el_new);
-      float xLp = INFINITY;
-      if (((dirp < 2) ? 1 : 0) == ph_new || el_new < d.yellow) xLp = d.length;
-      else if (lc0 != ld) xLp = tail0 + d.length;
-      px[ps].x = xLp;
+      // p's new leader slot (its last popped car) gets p's fake-leader x (:133): the value k_move
+      // used this tick (leadx).  It must NOT be recomputed from obs here - the lane of p's
+      // intersection stores the new phase / elapsed in this same kernel, and a lane that reads them
+      // afterwards would apply the light update twice (found by the round-1 fuzz run).
+      px[ps].x = d.leadx[idp];
     }
   }
   if (k_e > 0) {

@@ -567,7 +567,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
   const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_tpairs * sizeof(float) : 0), 256);
-  const size_t o_lead = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float) : 0), 256);
+  const size_t o_lead = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
       if (needs_serial(kpop, any_far, p.n_tot, C)) d.env_flag[env] = tick + 1;
       // the leader's x stays in its slot (after the write-back of the image, same wave)
       d.xv[(size_t)id * C + p.ld].x = p.xL;
+      d.leadx[id] = p.xL;  // k_advance re-installs it in the slot a pop frees (advance_road)
       my_updates += (unsigned long long)p.n_tot;
     }
   }

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(256) void k_move(const Dev d, const int tidx) {
       rx[slot] = make_float2(xn, vn);
       if (is_spawned && d.w) d.w[(size_t)id * C + slot] = (float)tick;
     }
-    if (active && k == 0) rx[ld].x = xL;  // the reference keeps the leader's x in its slot
+    if (active && k == 0) {
+      rx[ld].x = xL;  // the reference keeps the leader's x in its slot
+      d.leadx[id] = xL;  // and k_advance re-installs it in the slot a pop frees (advance_road)
+    }
 
     // ---- counts (move_cars :199-201, :208-212) and the pop prefix (:123) ---------------------
     const bool seg2 = (ld > lc) && (slot <= lc);  // wrapped ring, second segment: x tested, not v

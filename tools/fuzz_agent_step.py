@@ -1,0 +1,48 @@
+"""Randomised differential test of the fused agent step (tfx_agent_step: Repeater + Remi on the device,
+HIP graph replay) against the same wrappers emulated tick by tick on single-env oracles - random
+grid, capacity, batch, layout, decision length, periodic arrival density, with and without Remi,
+including decisions cut short by an overflow.  FUZZ_SECS (default 300)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "traffic-env_amd"), os.path.join(ROOT, "tests")]
+import numpy as np, torch
+from gym_traffic.core import TfxEngine
+from oracle.oracle import OracleEnv, live_mask
+from test_gpu_agent_step import emulate_agent_step
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+t0, n, early = time.time(), 0, 0
+while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
+    m, nn = int(rng.randint(1, 5)), int(rng.randint(1, 5))
+    C = int(rng.choice([4, 6, 10, 14, 20, 34, 66]))
+    L = float(rng.choice([40.0, 90.0, 150.0, 250.0]))
+    E = int(rng.choice([1, 3, 7, 33]))
+    layout = str(rng.choice(["ring", "transposed"]))
+    remi = bool(rng.randint(2)); T = int(rng.choice([2, 5, 10])); period = int(rng.choice([1, 2, 5, 9]))
+    eng = TfxEngine(m, nn, L, C, n_envs=E, planes=2 if layout == "transposed" else 3, layout=layout)
+    orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
+    ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+    eng.reset(ph)
+    for k, o in enumerate(orcs):
+        o.reset(ph[k])
+    eng.set_spawns(period=period)
+    for step in range(int(rng.choice([4, 10, 16]))):
+        act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        eng.set_actions(act)
+        tick0 = eng.tick
+        aobs, arew, adone = eng.agent_step(T, remi=remi)
+        eobs, erew, edone = emulate_agent_step(orcs, tick0, act, eng.entrypoints, T, remi, period)
+        assert np.array_equal(adone.cpu().numpy(), edone), (n, step, "done")
+        assert np.array_equal(aobs.cpu().numpy(), eobs), (n, step, "obs")
+        assert np.array_equal(arew.cpu().numpy(), erew), (n, step, "reward")
+        early += int(edone.sum())
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        xv = eng.xv.cpu().numpy()
+        for k, o in enumerate(orcs):
+            assert np.array_equal(ld[k], o.leading[0]) and np.array_equal(lc[k], o.lastcar[0]), (n, step, k)
+            live = live_mask(ld[k], lc[k], C)
+            assert np.array_equal(xv[k][live][:, 0].view(np.int32), o.x[0][live].view(np.int32)), (n, step, k)
+            assert np.array_equal(xv[k][live][:, 1].view(np.int32), o.v[0][live].view(np.int32)), (n, step, k)
+    n += 1
+    del eng
+print("agent-step fuzz ok: %d cases, %d env-decisions ended by an overflow, %.0f s" % (n, early, time.time() - t0))

@@ -60,6 +60,9 @@ while time.time() - t0 < LIMIT:
         for j in range(k): done |= orc.step(acts[j], roads[j])[2].astype(bool)
         assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (n, t)
         t += k
+        if rng.randint(4) == 0:        # the cold entry points too
+            assert np.array_equal(eng.cars_on_roads().cpu().numpy(), orc.cars_on_roads()), (n, t, "cars_on_roads")
+            assert np.array_equal(eng.remi_reward().cpu().numpy(), orc.remi_reward()), (n, t, "remi")
         if os.environ.get("FUZZ_DEBUG"):
             ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
             st = eng.planes_numpy()

@@ -234,3 +234,19 @@ def test_arrival_streams_in_c_equal_the_python_replay_and_numpy():
             for k, sch in enumerate(py):
                 a, b = sch.rand.get_state(), c_side.random_state(k).get_state()
                 assert np.array_equal(a[1], b[1]) and a[2] == b[2], (poisson, cpt, k)
+
+
+def test_arrival_streams_threads_do_not_change_the_streams(monkeypatch):
+    """Large calls are split over host threads (streams are independent): same result as one thread."""
+    from gym_traffic.spawner import ArrivalStreams
+    ent = np.arange(12, dtype=np.int32)
+    col = {int(rd): j for j, rd in enumerate(ent)}
+    seeds = list(range(700))
+    a = ArrivalStreams(seeds, True, ent, col, 12, 0.9)
+    monkeypatch.setenv("TFX_HOST_THREADS", "1")
+    ca, ma = [x.copy() for x in a.next_ticks(64)]
+    monkeypatch.setenv("TFX_HOST_THREADS", "6")
+    b = ArrivalStreams(seeds, True, ent, col, 12, 0.9)
+    cb, mb = b.next_ticks(64)
+    assert np.array_equal(ca, cb) and np.array_equal(ma, mb) and int(ma.sum()) > 10000
+    assert a.random_state(699).get_state()[2] == b.random_state(699).get_state()[2]

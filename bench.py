@@ -2,7 +2,10 @@
 """Headline benchmark: vehicle-updates/s of the IDM traffic-env tick on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without WORLD_SIZE in the environment: this process touches no GPU; it starts the N ranks
+    itself (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...),
+    relays rank 0's JSON line and exits with the ranks' return code.  Started under torchrun
+    (WORLD_SIZE set) it is one of those ranks.
 
 One "step" = one env tick (TrafficEnv._step, reference traffic_env.py:224-248) over EVERY env of
 the batch: the move kernel + the advance kernel.  Workload = BASELINE.json's headline single-GPU
@@ -113,6 +116,87 @@ def load_pmc_traffic(name, kernel):
         return None
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 and no WORLD_SIZE: start the N ranks as a child job, print rank 0's line, return
+    the job's exit code.  Nothing in this process initialises a GPU (torch.cuda.device_count() does
+    not on this image), nothing is exec'ed, a failed job is not retried."""
+    import subprocess
+    import torch
+    rehearsal = os.environ.get("TFX_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if not rehearsal and not a.selftest_launcher and have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (TFX_BENCH_REHEARSAL=1 runs every "
+                         "rank on GPU 0 over gloo as a dry run)\n" % (a.gpus, have))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    job = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, universal_newlines=True)
+    line = None
+    for out in job.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = job.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 3
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def selftest_rank(a):
+    """One rank of `--selftest-launcher`: gloo on the CPU, synthetic snapshots through RolloutGather,
+    the bench's reductions and the single JSON line - the N > 1 path minus the GPU."""
+    import torch
+    import torch.distributed as dist
+    from gym_traffic.distributed import RolloutGather
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == a.selftest_fail_rank:
+        return 7
+    if world > 1:
+        dist.init_process_group("gloo")
+    n, L, I = 3, 5, 2
+    g = RolloutGather(n, L, I, "cpu")
+    ok = True
+    for step in range(4):
+        base = 1000 * rank + 10 * step
+        g.start(torch.full((n, L), base, dtype=torch.int32), torch.full((n, I), base + 0.5),
+                torch.full((n,), step % 2, dtype=torch.uint8))
+    res = g.result()
+    if rank == 0:
+        obs, rew, done = res
+        want = torch.tensor([1000 * k + 30 for k in range(world) for _ in range(n)], dtype=torch.int32)
+        ok = (obs.shape == (world * n, L) and bool((obs[:, 0] == want).all()) and
+              bool((rew[:, 1] == want.float() + 0.5).all()) and bool((done == 1).all()) and
+              g.collectives == (4 if world > 1 else 0))
+    tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher_selftest", "value": float(ok), "unit": "ok", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "t_max": float(tt.item()),
+                          "data": "none: plumbing check, no kernel ran"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +206,15 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the N > 1 plumbing (parent launch, rendezvous, gather, relay); "
+                         "runs no kernel and measures nothing")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    if a.selftest_launcher:
+        sys.exit(selftest_rank(a))
 
     import numpy as np  # noqa: F401
     import torch
@@ -219,9 +311,10 @@ def main():
             "config": {"workload": wl.describe(a.config), "envs_per_gpu": E,
                        "grid": "%dx%d" % (c["m"], c["n"]), "cars_per_road_max": c["capacity"] - 2,
                        "car_layout": eng.layout,
-                       "parallelism": "env-sharded x%d%s" % (world, ", RCCL gather of obs/reward/done "
-                                                             "to rank 0 every %d ticks" % GATHER_EVERY
-                                                             if gather is not None else "")},
+                       "parallelism": "env-sharded x%d%s" % (
+                           world, ", one %s gather of (obs|reward|done) to rank 0 every %d ticks, double-"
+                           "buffered on a side stream" % ("gloo (rehearsal)" if rehearsal else "RCCL", GATHER_EVERY)
+                           if gather is not None else "")},
             "env_steps_per_sec": world * E * K / dt_max,
             "agent_steps_per_sec": world * E * K / dt_max / GATHER_EVERY,   # one decision = 10 ticks
             "mean_live_cars_per_road": live_per_tick / (E * eng.R),

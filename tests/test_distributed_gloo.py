@@ -123,3 +123,69 @@ def test_single_process_gather_is_a_snapshot():
     obs += 100                                            # live buffer moves on; the snapshot must not
     o, r, d = gth.result()
     assert o[0, 0].item() == 0 and torch.equal(r, torch.ones(3, 2)) and d.sum().item() == 0
+
+
+def _uneven_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gym_traffic.distributed import shard_range, RolloutGather
+        lo, hi = shard_range(7, rank, world)                       # 4 + 3 envs
+        n, L, I = hi - lo, 6, 2
+        g = RolloutGather(n, L, I, "cpu")
+        ids = torch.arange(lo, hi, dtype=torch.int32)
+        for step in range(5):                                      # starts never wait for the previous one
+            g.start(ids[:, None].repeat(1, L) + 100 * step, (ids[:, None].repeat(1, I) + 0.25).float(),
+                    (ids % 2).to(torch.uint8))
+            assert sum(w is not None for w in g.pending) <= g.DEPTH
+        res = g.result()
+        if rank == 0:
+            obs, rew, done = res
+            assert g.collectives == 5                              # ONE gather per snapshot
+            np.savez(os.path.join(out_dir, "uneven.npz"), obs=obs.numpy(), rew=rew.numpy(), done=done.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_shards_one_collective_per_snapshot(tmp_path):
+    mp.spawn(_uneven_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), "uneven.npz"))
+    ids = np.arange(7)
+    assert np.array_equal(z["obs"], np.repeat(ids[:, None], 6, 1) + 400)
+    assert np.array_equal(z["rew"], np.repeat(ids[:, None], 2, 1) + 0.25)
+    assert np.array_equal(z["done"], ids % 2)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE: the parent starts the ranks (torchrun, 127.0.0.1),
+    relays exactly one JSON line and returns the job's exit code - here with the CPU-only plumbing
+    check in place of the GPU step."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launcher"]
+    ok = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                        timeout=240)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] == 1.0 and out["t_max"] == 2.0
+    bad = subprocess.run(cmd + ["--selftest-fail-rank", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=240)
+    assert bad.returncode != 0 and bad.stdout.strip() == ""        # a failed rank: no line, non-zero exit
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "TFX_BENCH_REHEARSAL")}
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=120)
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""

@@ -144,3 +144,84 @@ def test_cfg4_capacity_two_pass_tiled_kernel_vs_oracle(layout):
         assert int((lc != ld).sum()) > 1000 and int(eng.cars_on_roads_flat().max()) > 64
     finally:
         del wl.CONFIGS["_cfg4_tiled"]
+
+
+@pytest.mark.parametrize("layout", ["transposed", "ring"])
+@pytest.mark.parametrize("lcps", [0.12, 0.02])
+def test_cfg4_real_size_closed_loop_vs_oracle(layout, lcps):
+    """BASELINE config 5 at its real size: GridRoad(64, 64, 800), CAPACITY = 130, one env, empty start,
+    on-device Poisson arrivals (local_cars_per_sec 0.12 -> 15.36 cars/tick nominal, which the
+    reference's whole-tick gap rounding turns into bursts of thousands: traffic_env.py:160-164) and the
+    greedy controller every 3 ticks (greedy.py:14-16 on cars_on_roads, traffic_env.py:255-257), 150
+    ticks.  The oracle is fed by the host mirror of the device stream and the greedy rule evaluated
+    on its own counts; ring indices, obs, rewards, done every tick, every live car at the end."""
+    from gym_traffic.core import TfxEngine
+    from gym_traffic.devrng import PoissonMirror
+    m = n = 64
+    C, L, T, spacing, seed = 130, 800.0, 150, 3, 1234
+    cpt = lcps * m * 4 * 0.5
+    eng = TfxEngine(m, n, L, C, n_envs=1, planes=2, layout=layout)
+    assert (eng.R, eng.I) == (16640, 4096)
+    orc = OracleEnv(m, n, L, C, eng.dest, eng.phases, eng.nexts, n_envs=1)
+    ph = np.zeros((1, eng.I), np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    eng.set_poisson(cpt, seed=seed)
+    eng.set_greedy(spacing)
+    mirror = PoissonMirror(cpt, seed, eng.n_entry, [0])
+    entry = np.asarray(eng.entrypoints)
+    act = np.zeros((1, eng.I), np.int32)
+    arrived = overflow_ticks = 0
+    for t in range(T):
+        if t % spacing == 0:
+            c = orc.cars_on_roads()
+            act = (c.reshape(1, eng.I, 4).dot([1, 1, -1, -1]) < 0).astype(np.int32)
+        cnt = mirror.next_tick()
+        arrived += int(cnt.sum())
+        eng.step(1)
+        _, _, od = orc.step(act, [np.repeat(entry, cnt[0])], nthreads=8)
+        overflow_ticks += int(od[0])
+        assert np.array_equal(eng.done.cpu().numpy(), od), t
+        assert np.array_equal(eng.leading.cpu().numpy(), orc.leading), t
+        assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), t
+        assert np.array_equal(eng.obs.cpu().numpy(), orc.obs), t
+        assert np.array_equal(eng.rewards.cpu().numpy(), orc.rewards), t
+    assert arrived > 0.5 * cpt * T
+    assert (overflow_ticks > 50) == (lcps == 0.12)        # the nominal rate saturates the entry roads
+    ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+    x, v, _ = eng.planes_numpy()
+    live = live_mask(ld[0], lc[0], C)
+    assert int(live.sum()) > 300
+    assert np.array_equal(x[0][live].view(np.int32), orc.x[0][live].view(np.int32))
+    assert np.array_equal(v[0][live].view(np.int32), orc.v[0][live].view(np.int32))
+    assert np.array_equal(eng.waiting.cpu().numpy(), orc.waiting)
+
+
+def test_cfg4_sixteen_envs_properties():
+    """cfg4 x 16 envs, closed loop on the device: an env's trajectory does not depend on the batch it
+    runs in (global env 5 and 15 alone give the same rings), ring indices stay in range, cars are
+    conserved up to arrivals."""
+    from gym_traffic.core import TfxEngine
+    m = n = 64
+    cpt = 0.12 * m * 4 * 0.5
+
+    def make(E, off):
+        e = TfxEngine(m, n, 800.0, 130, n_envs=E, planes=2, env_id_offset=off)
+        e.reset(np.zeros((1, e.I), np.int32))
+        e.set_poisson(cpt, seed=1234)
+        e.set_greedy(3)
+        return e
+    eng = make(16, 0)
+    solos = {k: make(1, k) for k in (5, 15)}
+    for _ in range(6):
+        eng.step(10)
+        for s in solos.values():
+            s.step(10)
+    ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+    assert ld.min() >= 1 and lc.min() >= 1 and ld.max() <= 129 and lc.max() <= 129
+    for k, s in solos.items():
+        assert torch.equal(s.leading[0], eng.leading[k]) and torch.equal(s.lastcar[0], eng.lastcar[k]), k
+        assert torch.equal(s.obs[0], eng.obs[k]), k
+    occ = eng.cars_on_roads_flat().cpu().numpy()
+    assert occ.max() == 128 and (occ.sum(1) > 10000).all()
+    assert len({int(v) for v in occ.sum(1)}) > 1          # the envs diverge (own arrival streams)

@@ -154,14 +154,14 @@ def test_free_running_vs_oracle_and_golden(name, golden_cache):
         assert np.array_equal(eng.trip_times[0, :n].cpu().numpy(), orc.trip_times[0, :n])
 
 
-@pytest.mark.parametrize("name", ["g2x2_s0_poi_c10", "g2x2_s1_reg_c20", "g2x2_learnswitch", "g3x3_default",
-                                  "g2x2_const0_jam"])
+@pytest.mark.parametrize("name", [n for n in golden_names() if "ints" not in n])
 def test_teacher_forced_vs_golden(name, golden_cache):
-    """Reference state at t -> one tfx_step -> reference state at t+1: ints exact, x/v <= 1 ulp."""
+    """Reference state at t -> one tfx_step -> reference state at t+1: ints exact, x/v <= 1 ulp.
+    Every fixture that carries per-tick states, every tick."""
     g = golden_cache(name)
     sc = g.sc
     eng = engine_for(g)
-    for t in range(0, sc["T"], 2):
+    for t in range(0, sc["T"]):
         eng.load_state(g["state_x"][t][None], g["state_v"][t][None], g["leading"][t][None],
                        g["lastcar"][t][None], w=g["state_w"][t][None])
         eng.obs.copy_(torch.as_tensor(g["obs"][t][None]))

@@ -1,0 +1,173 @@
+"""Pins for defects found outside the suite (round-1 fuzz run, round-1 review), plus a time-bounded
+slice of the randomised differential test (tools/fuzz_vs_oracle.py) so that the suite itself keeps
+sampling new configurations.  Everything goes through the C ABI; the oracle is the checker."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN_DIR
+from oracle.oracle import OracleEnv, live_mask
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from gym_traffic.core import TfxEngine  # noqa: E402
+from gym_traffic.devrng import PoissonMirror  # noqa: E402
+
+
+def test_ring_advance_leader_x_race_pin():
+    """Commit 0b40755: on the ring layout k_advance re-installed a popped road's fake-leader x by
+    re-deriving it from the phase / elapsed words that another lane of the same kernel was storing
+    (scheduling dependent: the light update could be applied twice).  The fixture holds the shape of
+    the fuzz case that exposed it - many envs (so the lanes of one intersection's roads and the lane
+    storing its light words sit in different wavefronts), short roads that pop cars every tick and a
+    fresh random action every tick (so the light words change under the readers).  The fake leader's
+    x of every road is compared with the oracle after every tick."""
+    from test_gpu_parity import assert_same_state, counts, random_state, load_both
+    case = json.load(open(os.path.join(GOLDEN_DIR, "regress", "ring_advance_race.json")))
+    rng = np.random.RandomState(case["seed"])
+    m, n, C, L, E = case["m"], case["n"], case["C"], case["L"], case["E"]
+    eng = TfxEngine(m, n, L, C, n_envs=E, rate=case["rate"], planes=3, layout="ring")
+    orc = OracleEnv(m, n, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, rate=case["rate"])
+    x, v, w, ld, lc = random_state(rng, E, eng.R, C, L, crowd=case["crowd"], beyond=case["beyond"], sorted_x=True)
+    ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+    el = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
+    load_both(eng, orc, x, v, w, ld, lc, ph, el)
+    eng.set_tick(60)
+    orc.steps[:] = 60
+    pops = 0
+    for t in range(case["T"]):
+        act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        roads = [rng.choice(eng.entrypoints, size=rng.poisson(case["dens"])).tolist() for _ in range(E)]
+        eng.set_actions(act)
+        eng.set_spawns(counts=counts(eng, roads))
+        eng.step(1)
+        orc.step(act, roads)
+        pops += int(orc.passed.sum())
+        assert_same_state(eng, orc, "tick %d" % t)       # includes every road's fake-leader x
+    assert pops > 5 * case["T"]                          # the popped-road path ran all the time
+
+
+def test_agent_graph_follows_a_new_poisson_stream():
+    """the captured agent-step graph baked the Poisson seed / table length into kernel
+    arguments that were not part of its key, and tfx_set_poisson usually re-allocates at the same
+    address - a re-seed between decisions was silently ignored."""
+    E, m, n, L, cap = 4, 3, 3, 150.0, 30
+    eng = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    orc = OracleEnv(m, n, L, cap, eng.dest, eng.phases, eng.nexts, n_envs=E)
+    ph = np.zeros((E, eng.I), np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    eng.set_actions(cycle_period=7)
+    tick = 0
+    for seed, cpt in ((11, 1.5), (99, 0.4), (11, 0.9)):          # third: old seed, other (shorter) table
+        eng.set_poisson(cpt, seed=seed)
+        mirror = PoissonMirror(cpt, seed, eng.n_entry, range(E))
+        for _ in range(2):
+            eng.agent_step(5, remi=True)
+            for _t in range(5):
+                cnt = mirror.next_tick()
+                roads = [[int(eng.entrypoints[j]) for j in range(eng.n_entry) for _ in range(cnt[k, j])]
+                         for k in range(E)]
+                act = np.repeat((((tick + np.arange(E) % 7) // 7) & 1).astype(np.int32)[:, None], eng.I, 1)
+                orc.step(act, roads)
+                tick += 1
+            orc.remi_reward()
+            assert int(eng.done_tick.max()) == 0
+            assert np.array_equal(eng.leading.cpu().numpy(), orc.leading), (seed, cpt)
+            assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), (seed, cpt)
+    assert int(eng.cars_on_roads_flat().sum()) > 30
+
+
+def test_reset_done_after_a_fused_decision():
+    """reset_done() defaulted to flags agent_step never refreshed."""
+    from gym_traffic.envs.vec_env import TrafficVecEnv
+    env = TrafficVecEnv(6, 2, 2, 60.0, capacity=6, spawn='none', seed=3)
+    eng = env.engine
+    env.reset(np.zeros((6, eng.I), np.int32))
+    # only env 4 gets arrivals: it jams against the red lights and overflows within a few decisions
+    cnt = np.zeros((12, 6, eng.n_entry), np.int32)
+    cnt[:, 4, :] = 1
+    hit = None
+    for step in range(12):
+        eng.set_spawns(counts=cnt[:10], per_tick=True)
+        _, _, adone = env.agent_step(np.zeros((6, eng.I), np.int32), n_ticks=10)
+        if int(adone.sum()):
+            hit = adone.cpu().numpy().copy()
+            break
+    assert hit is not None and hit.tolist() == [0, 0, 0, 0, 1, 0]
+    assert np.array_equal(eng.done.cpu().numpy(), hit)            # the default mask IS the decision's
+    before = eng.cars_on_roads_flat().cpu().numpy().copy()
+    mask = env.reset_done()
+    assert np.array_equal(mask.cpu().numpy(), hit)
+    after = eng.cars_on_roads_flat().cpu().numpy()
+    assert after[4].sum() == 0 and before[4].sum() > 0
+    assert np.array_equal(after[[0, 1, 2, 3, 5]], before[[0, 1, 2, 3, 5]])
+
+
+def test_index_write_through_view_keeps_the_cars():
+    """`env.lastcar[i] = k` on the transposed layout pushed a stale staging copy over the
+    live cars.  Ring semantics: the cars keep their slots; the write only changes which are live."""
+    import gym_traffic  # noqa: F401
+    import gym
+    from gym_traffic.envs.roadgraph import GridRoad
+    env = gym.make('traffic-v0')
+    env.set_graph(GridRoad(2, 2, 120), capacity=12)
+    env.seed_generator(5)
+    env.reset_entrypoints()
+    np.random.seed(5)
+    env.reset()
+    for _ in range(60):
+        env.step(env.action_space.sample())
+    eng = env.engine
+    assert eng.layout == "transposed"
+    ld, lc = np.asarray(env.leading).copy(), np.asarray(env.lastcar).copy()
+    n = (lc - ld) % (eng.C - 1)
+    road = int(np.argmax(n))
+    assert n[road] >= 2
+    st0 = env.state.numpy().copy()
+    env.step(env.action_space.sample())                   # the staging copy is now one tick old
+    ld, lc = np.asarray(env.leading).copy(), np.asarray(env.lastcar).copy()
+    st1 = env.state.numpy().copy()
+    eng._epoch += 1                                       # as if the cars had moved since that read
+    new_lc = int(lc[road]) - 1 if lc[road] > 1 else eng.C - 1
+    env.lastcar[road] = new_lc                            # drop the road's last car
+    lc2 = lc.copy()
+    lc2[road] = new_lc
+    assert np.array_equal(np.asarray(env.lastcar), lc2)
+    st2 = env.state.numpy()
+    live = live_mask(ld, lc2, eng.C)
+    assert np.array_equal(st2[:, 0, :][live].view(np.int32), st1[:, 0, :][live].view(np.int32))
+    assert np.array_equal(st2[:, 1, :][live].view(np.int32), st1[:, 1, :][live].view(np.int32))
+    assert not np.array_equal(st1[:, 0, :][live], st0[:, 0, :][live])
+    # and the engine keeps stepping consistently from there (tail cache rebuilt)
+    env.step(env.action_space.sample())
+
+
+def test_transposed_handle_allocates_no_ring_copy_until_asked():
+    """The ring-shaped staging copy of a transposed handle is made on first use only."""
+    from gym_traffic import workload as wl
+    eng = TfxEngine(4, 4, 200.0, 34, n_envs=64, planes=2)
+    eng.reset(np.zeros((1, eng.I), np.int32))
+    eng.set_spawns(period=4)
+    eng.set_actions(cycle_period=10)
+    eng.step(50)
+    assert eng._ring is None
+    x = eng.x
+    assert eng._ring is not None and float(x.abs().sum()) > 0
+
+
+def test_fuzz_slice_vs_oracle():
+    """~16 s of tools/fuzz_vs_oracle.py (two seeds derived from the date, so successive rounds sample
+    different cases): random shapes, layouts, pathological start states, validate mode."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_vs_oracle as fz
+    day = int(time.strftime("%Y%m%d"))
+    total = 0
+    for seed in (day, day + 1):
+        total += fz.run(seed, secs=8.0)
+    assert total >= 4

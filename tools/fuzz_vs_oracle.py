@@ -18,69 +18,90 @@ from gym_traffic.core import TfxEngine
 from oracle.oracle import OracleEnv
 from test_gpu_parity import assert_same_state, counts, random_state, load_both
 import pickle
-rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-if len(sys.argv) > 2:
-    rng.set_state(pickle.load(open(sys.argv[2], "rb")))
-t0 = time.time(); n = 0
-LIMIT = float(os.environ.get("FUZZ_SECS", "420"))
-while time.time() - t0 < LIMIT:
-    os.makedirs("gpurun_out", exist_ok=True)
-    pickle.dump(rng.get_state(), open("gpurun_out/fuzz_case_start.pkl", "wb"))
-    m, nn = int(rng.randint(1, 7)), int(rng.randint(1, 7))
-    C = int(rng.choice([3, 4, 5, 8, 10, 16, 20, 33, 34, 50, 66, 90, 130]))
-    L = float(rng.choice([30.0, 75.0, 140.0, 250.0, 400.0]))
-    rate = float(rng.choice([0.25, 0.5, 1.0]))
-    ls = bool(rng.randint(2)); val = bool(rng.randint(3) == 0)
-    spec = int(rng.choice([0, 0, 0b0001, 0b1010, 0b1110, 0b0110]))
-    E = int(rng.choice([1, 2, 3, 9, 40, 130]))
-    layout = str(rng.choice(["ring", "transposed", "transposed"]))
-    os.environ.pop("TFX_LINES", None); os.environ.pop("TFX_KINDS", None)
-    mode = rng.randint(3)
-    if layout == "transposed" and not val and mode == 1: os.environ["TFX_LINES"] = "1"
-    if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
-    planes = 3 if (val or layout == "ring") else 2
-    eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)
-    orc = OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, rate=rate, learn_switch=ls, validate=val)
-    if rng.randint(2):
-        x, v, w, ld, lc = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.2, 0.6, 0.9]), beyond=rng.choice([0.0, 0.1, 0.5, 1.7]), sorted_x=bool(rng.randint(2)))
-        ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); el = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
-        load_both(eng, orc, x, v, w, ld, lc, ph, el)
-        eng.set_tick(60); orc.steps[:] = 60; orc.n_trips[:] = 0
-        if val: eng.n_trips.zero_()
-    else:
-        ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); eng.reset(ph); orc.reset(ph)
-    dens = rng.choice([0.1, 0.6, 2.0]); t = 0; T = int(rng.choice([8, 30, 60]))
-    while t < T:
-        k = int(min(T - t, rng.choice([1, 1, 2, 5, 10])))
-        acts = rng.randint(2, size=(k, E, eng.I)).astype(np.int32)
-        roads = [[(rng.choice(eng.entrypoints, size=rng.poisson(dens)).tolist() if eng.n_entry else []) for _ in range(E)] for _ in range(k)]
-        eng.set_actions(acts, per_tick=True); eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
-        eng.step(k)
-        done = np.zeros(E, bool)
-        for j in range(k): done |= orc.step(acts[j], roads[j])[2].astype(bool)
-        assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (n, t)
-        t += k
-        if rng.randint(4) == 0:        # the cold entry points too
-            assert np.array_equal(eng.cars_on_roads().cpu().numpy(), orc.cars_on_roads()), (n, t, "cars_on_roads")
-            assert np.array_equal(eng.remi_reward().cpu().numpy(), orc.remi_reward()), (n, t, "remi")
-        if os.environ.get("FUZZ_DEBUG"):
-            ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
-            st = eng.planes_numpy()
-            rows = np.arange(eng.R)
-            for kk in range(E):
-                a = st[0][kk][rows, ldh[kk]]; b = orc.x[kk][rows, ldh[kk]]
-                bad = np.nonzero(~((a.view(np.int32) == b.view(np.int32)) | (np.isnan(a) & np.isnan(b))))[0]
-                for e in bad:
-                    nx = int(eng.nexts[e])
-                    print("tick", t, "env", kk, "road", e, "next", nx, "dest", eng.dest[e], "gpu leader x", a[e], "oracle", b[e],
-                          "ld/lc", ldh[kk, e], lch[kk, e], "orc ld/lc", orc.leading[kk, e], orc.lastcar[kk, e],
-                          "next ld/lc", (ldh[kk, nx], lch[kk, nx]) if nx >= 0 else None,
-                          "phase/elapsed", eng.obs[kk, 2*eng.r + e % eng.I].item() if e < eng.r else None, eng.obs[kk, 2*eng.r + eng.I + e % eng.I].item() if e < eng.r else None,
-                          "next tail gpu/orc", (st[0][kk][nx, lch[kk, nx]], orc.x[kk][nx, orc.lastcar[kk, nx]]) if nx >= 0 else None)
-        assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d) tick %d" % (n, m, nn, C, E, layout, val, mode, t))
-    if val:
-        nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n
-        for kk in range(E): assert np.array_equal(eng.trip_times[kk, :min(nt[kk], eng.trip_cap)].cpu().numpy(), orc.trip_times[kk, :min(nt[kk], eng.trip_cap)]), n
-    n += 1
-    del eng
-print("fuzz ok: %d cases in %.0f s" % (n, time.time() - t0))
+
+
+def run(seed, secs=420.0, state_file=None):
+    """Random cases for `secs` seconds; returns the number of cases run (asserts on any mismatch)."""
+    rng = np.random.RandomState(int(seed))
+    if state_file:
+        rng.set_state(pickle.load(open(state_file, "rb")))
+    LIMIT = float(secs)
+    keep = {k: os.environ.get(k) for k in ("TFX_LINES", "TFX_KINDS")}
+    try:
+        return _run(rng, seed, LIMIT)
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _run(rng, seed, LIMIT):
+    t0 = time.time(); n = 0
+    while time.time() - t0 < LIMIT:
+        os.makedirs("gpurun_out", exist_ok=True)
+        pickle.dump(rng.get_state(), open("gpurun_out/fuzz_case_start.pkl", "wb"))
+        m, nn = int(rng.randint(1, 7)), int(rng.randint(1, 7))
+        C = int(rng.choice([3, 4, 5, 8, 10, 16, 20, 33, 34, 50, 66, 90, 130]))
+        L = float(rng.choice([30.0, 75.0, 140.0, 250.0, 400.0]))
+        rate = float(rng.choice([0.25, 0.5, 1.0]))
+        ls = bool(rng.randint(2)); val = bool(rng.randint(3) == 0)
+        spec = int(rng.choice([0, 0, 0b0001, 0b1010, 0b1110, 0b0110]))
+        E = int(rng.choice([1, 2, 3, 9, 40, 130]))
+        layout = str(rng.choice(["ring", "transposed", "transposed"]))
+        os.environ.pop("TFX_LINES", None); os.environ.pop("TFX_KINDS", None)
+        mode = rng.randint(3)
+        if layout == "transposed" and not val and mode == 1: os.environ["TFX_LINES"] = "1"
+        if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
+        planes = 3 if (val or layout == "ring") else 2
+        eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)
+        orc = OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, rate=rate, learn_switch=ls, validate=val)
+        if rng.randint(2):
+            x, v, w, ld, lc = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.2, 0.6, 0.9]), beyond=rng.choice([0.0, 0.1, 0.5, 1.7]), sorted_x=bool(rng.randint(2)))
+            ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); el = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
+            load_both(eng, orc, x, v, w, ld, lc, ph, el)
+            eng.set_tick(60); orc.steps[:] = 60; orc.n_trips[:] = 0
+            if val: eng.n_trips.zero_()
+        else:
+            ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); eng.reset(ph); orc.reset(ph)
+        dens = rng.choice([0.1, 0.6, 2.0]); t = 0; T = int(rng.choice([8, 30, 60]))
+        while t < T:
+            k = int(min(T - t, rng.choice([1, 1, 2, 5, 10])))
+            acts = rng.randint(2, size=(k, E, eng.I)).astype(np.int32)
+            roads = [[(rng.choice(eng.entrypoints, size=rng.poisson(dens)).tolist() if eng.n_entry else []) for _ in range(E)] for _ in range(k)]
+            eng.set_actions(acts, per_tick=True); eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+            eng.step(k)
+            done = np.zeros(E, bool)
+            for j in range(k): done |= orc.step(acts[j], roads[j])[2].astype(bool)
+            assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (n, t)
+            t += k
+            if rng.randint(4) == 0:        # the cold entry points too
+                assert np.array_equal(eng.cars_on_roads().cpu().numpy(), orc.cars_on_roads()), (n, t, "cars_on_roads")
+                assert np.array_equal(eng.remi_reward().cpu().numpy(), orc.remi_reward()), (n, t, "remi")
+            if os.environ.get("FUZZ_DEBUG"):
+                ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+                st = eng.planes_numpy()
+                rows = np.arange(eng.R)
+                for kk in range(E):
+                    a = st[0][kk][rows, ldh[kk]]; b = orc.x[kk][rows, ldh[kk]]
+                    bad = np.nonzero(~((a.view(np.int32) == b.view(np.int32)) | (np.isnan(a) & np.isnan(b))))[0]
+                    for e in bad:
+                        nx = int(eng.nexts[e])
+                        print("tick", t, "env", kk, "road", e, "next", nx, "dest", eng.dest[e], "gpu leader x", a[e], "oracle", b[e],
+                              "ld/lc", ldh[kk, e], lch[kk, e], "orc ld/lc", orc.leading[kk, e], orc.lastcar[kk, e],
+                              "next ld/lc", (ldh[kk, nx], lch[kk, nx]) if nx >= 0 else None,
+                              "phase/elapsed", eng.obs[kk, 2*eng.r + e % eng.I].item() if e < eng.r else None, eng.obs[kk, 2*eng.r + eng.I + e % eng.I].item() if e < eng.r else None,
+                              "next tail gpu/orc", (st[0][kk][nx, lch[kk, nx]], orc.x[kk][nx, orc.lastcar[kk, nx]]) if nx >= 0 else None)
+            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d) tick %d" % (n, m, nn, C, E, layout, val, mode, t))
+        if val:
+            nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n
+            for kk in range(E): assert np.array_equal(eng.trip_times[kk, :min(nt[kk], eng.trip_cap)].cpu().numpy(), orc.trip_times[kk, :min(nt[kk], eng.trip_cap)]), n
+        n += 1
+        del eng
+    print("fuzz ok: seed %d, %d cases in %.0f s" % (seed, n, time.time() - t0))
+    return n
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, float(os.environ.get("FUZZ_SECS", "420")),
+        sys.argv[2] if len(sys.argv) > 2 else None)

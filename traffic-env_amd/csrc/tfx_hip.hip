@@ -83,6 +83,10 @@ struct tfx_handle_s {
   hipGraphExec_t ag_exec = nullptr;
   hipStream_t ag_stream = nullptr;
   std::string ag_key;
+  // bumped by every call that changes something a captured kernel argument was built from (bound
+  // buffers, action / spawn rules, the Poisson stream): part of the graph key, so a stale graph is
+  // never replayed even when a re-allocated buffer lands on the address the old one had
+  unsigned long long input_gen = 0;
   bool use_graph = true;  // TFX_GRAPH=0 disables
   bool size_only = false;
   // on-device Poisson arrivals / greedy controller (own buffers)
@@ -442,8 +446,9 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   const Dev &d = h->d;
   if (!h->use_graph) return agent_sequence(h, n_ticks, remi, aobs, areward, adone, st);
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
-  char key[512];
-  snprintf(key, sizeof key, "%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p", (int)h->poisson,
+  char key[640];
+  snprintf(key, sizeof key, "%llu|%u|%u|%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
+           h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, (int)h->poisson,
            (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, (void *)aobs,
            (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
            (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
@@ -668,6 +673,7 @@ int tfx_bind_buffers(tfx_handle h, const tfx_buffers *b) {
   d.done_tick = b->done_tick; d.trip_times = b->trip_times; d.n_trips = b->n_trips;
   d.trip_cap = b->trip_cap;
   h->bound = true;
+  ++h->input_gen;
   return TFX_OK;
 }
 
@@ -703,6 +709,7 @@ int tfx_refresh(tfx_handle h, void *stream) {
 int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick) {
   if (int rc = check_handle(h, false)) return rc;
   Dev &d = h->d;
+  ++h->input_gen;
   h->greedy = false;
   if (mode == TFX_ACTION_GREEDY) {
     if (period < 1) return fail(TFX_EINVAL, "greedy spacing must be >= 1");
@@ -736,6 +743,7 @@ int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t peri
 int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t period, int32_t per_tick) {
   if (int rc = check_handle(h, false)) return rc;
   Dev &d = h->d;
+  ++h->input_gen;
   h->poisson = false;
   if (mode == TFX_SPAWN_PERIODIC) {
     if (period < 1) return fail(TFX_EINVAL, "spawn period must be >= 1");
@@ -758,6 +766,7 @@ int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uin
   if (!cdf || n_cdf < 1 || n_cdf > 65536) return fail(TFX_EINVAL, "gap table missing or too long");
   Dev &d = h->d;
   if (d.n_entry < 1) return fail(TFX_EINVAL, "no entry roads");
+  ++h->input_gen;
   if (h->dev_ps) { (void)hipFree(h->dev_ps); h->dev_ps = nullptr; }
   const size_t n_counts = (size_t)d.E * d.n_entry;
   const size_t bytes = (n_counts + 2 * (size_t)d.E + (size_t)n_cdf) * 4;

@@ -95,18 +95,25 @@ class TfxEngine(object):
         dev = self.device
         # zeros, not empty: the reference leaves these to np.empty garbage; a defined start keeps
         # runs reproducible (dead slots are never read)
-        self._ring = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
         if self.layout == "transposed":
             pairs = C.c_int64()
             nat.check(self.lib.tfx_xv_pairs(h, C.byref(pairs)))
             self._t = torch.zeros((int(pairs.value), 2), dtype=torch.float32, device=dev)
+            # the ring-shaped staging copy behind `xv` / `x` / `v` / `w` / load_state is made on first
+            # use: a rollout that never looks at the cars does not pay a second copy of them
+            self._ring = None
+            self._ringw = None
+            self._tw = torch.zeros((self._t.shape[0],), dtype=torch.float32, device=dev) if P == 3 else None
         else:
             self._t = None
-        # spawn ticks (validate mode): ring-shaped array (the live one on the ring layout, a staging copy
-        # on the transposed layout, whose own w buffer is T-shaped like the cars)
-        self._ringw = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
-        self._tw = (torch.zeros((self._t.shape[0],), dtype=torch.float32, device=dev)
-                    if (P == 3 and self._t is not None) else None)
+            self._ring = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
+            # spawn ticks (validate mode): ring-shaped like the cars
+            self._ringw = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
+            self._tw = None
+        # transposed handles: `_epoch` counts calls that move the cars; the staging copy mirrors the
+        # device state only while `_stage_epoch` equals it
+        self._epoch = 0
+        self._stage_epoch = -1
         self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.obs = torch.zeros((E, self.obs_len), dtype=torch.int32, device=dev)
@@ -142,10 +149,18 @@ class TfxEngine(object):
         self.elapsed = self.obs[:, 2 * r + I:]
 
     # ---- car state in the reference's ring layout -----------------------------------------------
+    def _staging(self):
+        if self._ring is None:
+            self._ring = torch.zeros((self.E, self.R, self.C, 2), dtype=torch.float32, device=self.device)
+            if self.P == 3:
+                self._ringw = torch.zeros((self.E, self.R, self.C), dtype=torch.float32, device=self.device)
+
     def _export(self):
         if self._t is not None:
+            self._staging()
             with torch.cuda.device(self.device):
                 nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
+            self._stage_epoch = self._epoch
 
     @property
     def xv(self):
@@ -157,7 +172,7 @@ class TfxEngine(object):
     @property
     def w(self):
         """[E,R,C] spawn tick by ring slot (None unless planes == 3); same staging rule as `xv`."""
-        if self._ringw is None:
+        if self.P != 3:
             return None
         self._export()
         return self._ringw
@@ -189,6 +204,7 @@ class TfxEngine(object):
             np.asarray(phase_init, np.int32), (self.E, self.I)))).to(self.device)
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_reset(self.h, _ptr(ph), self._stream()))
+        self._epoch += 1
         self._keep = ph
         self.tick = 0
         self.done.zero_()
@@ -203,14 +219,19 @@ class TfxEngine(object):
         ph = ph.to(device=self.device, dtype=torch.int32).contiguous()
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_reset_envs(self.h, _ptr(ph), _ptr(m), self._stream()))
+        self._epoch += 1
         self._keep = (ph, m)
         self.done.masked_fill_(m.bool(), 0)
 
     def refresh(self):
         """After writing xv / leading / lastcar from outside: push the ring-layout staging copy to
-        the device layout (transposed handles) and rebuild the tail cache."""
+        the device layout (transposed handles) and rebuild the tail cache.  The staging copy is pushed
+        only if it was brought up to date (an `xv` / `x` / `v` / `w` access, `_export()` or
+        load_state) since the cars last moved - a stale one would overwrite the live cars.  Ring
+        semantics for a write to leading / lastcar alone therefore need `_export()` BEFORE the write
+        (the env's DeviceViews do that); without it the k-th car of a road stays its k-th car."""
         with torch.cuda.device(self.device):
-            if self._t is not None:
+            if self._t is not None and self._ring is not None and self._stage_epoch == self._epoch:
                 nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 
@@ -225,8 +246,10 @@ class TfxEngine(object):
 
     def set_greedy(self, spacing=3):
         """On-device greedy controller (algorithms/greedy.py:14-16), a decision every `spacing` ticks."""
-        nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_GREEDY, None, int(spacing), 0))
-        self._action_bound = None
+        key = ("greedy", int(spacing))
+        if self._action_bound != key:
+            nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_GREEDY, None, int(spacing), 0))
+            self._action_bound = key
 
     def set_actions(self, actions=None, cycle_period=None, per_tick=False):
         """actions: int tensor/array [E,I] (or [I] broadcast; with per_tick a leading n_ticks
@@ -235,8 +258,10 @@ class TfxEngine(object):
         one, so the bound pointer - and any captured graph - stays valid from call to call; a
         per-tick device tensor is bound as it is (zero copy)."""
         if cycle_period is not None:
-            nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_CYCLE, None, int(cycle_period), 0))
-            self._action_bound = None
+            key = ("cycle", int(cycle_period))
+            if self._action_bound != key:      # an unchanged rule keeps the captured agent-step graph
+                nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_CYCLE, None, int(cycle_period), 0))
+                self._action_bound = key
             return
         a, owned = self._as_dev_i32(actions, "act_pt" if per_tick else "act")
         if per_tick:
@@ -259,8 +284,10 @@ class TfxEngine(object):
         """counts: int [E,n_entry] (with per_tick: [n_ticks,E,n_entry]); period: on-device
         one-car-every-`period`-ticks per entry road; neither: no spawns.  Buffers as in set_actions."""
         if period is not None:
-            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_PERIODIC, None, int(period), 0))
-            self._spawn_bound = None
+            key = ("periodic", int(period))
+            if self._spawn_bound != key:
+                nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_PERIODIC, None, int(period), 0))
+                self._spawn_bound = key
         elif counts is not None:
             c, owned = self._as_dev_i32(counts, "spawn_pt" if per_tick else "spawn")
             if per_tick:
@@ -276,9 +303,9 @@ class TfxEngine(object):
             if self._spawn_bound != key:
                 nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1 if per_tick else 0))
                 self._spawn_bound = key
-        else:
+        elif self._spawn_bound != ("none",):
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_NONE, None, 0, 0))
-            self._spawn_bound = None
+            self._spawn_bound = ("none",)
 
     def _as_dev_i32(self, a, key):
         """-> (int32 device tensor, owned).  Device tensors pass through (owned False).  Host arrays
@@ -310,6 +337,7 @@ class TfxEngine(object):
         """n_ticks x TrafficEnv._step (traffic_env.py:224-248) with the inputs set by
         set_actions / set_spawns.  Updates `done` (overflow in any of these ticks)."""
         first = self.tick
+        self._epoch += 1
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_step(self.h, int(n_ticks), self._stream()))
             self.tick += int(n_ticks)
@@ -322,7 +350,9 @@ class TfxEngine(object):
         if getattr(self, "_aobs", None) is None:
             self._aobs = torch.zeros((self.E, 2 * self.r + self.I), dtype=torch.float32, device=self.device)
             self._arew = torch.zeros((self.E, self.I), dtype=torch.float32, device=self.device)
-            self._adone = torch.zeros((self.E,), dtype=torch.uint8, device=self.device)
+            # the decision's done flags ARE the engine's `done` (what reset_done() defaults to)
+            self._adone = self.done
+        self._epoch += 1
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_agent_step(self.h, int(n_ticks), int(bool(remi)), _ptr(self._aobs),
                                               _ptr(self._arew), _ptr(self._adone), self._stream()))
@@ -330,11 +360,13 @@ class TfxEngine(object):
         return self._aobs, self._arew, self._adone
 
     def move_cars(self):
+        self._epoch += 1
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_move_cars(self.h, self._stream()))
 
     def advance_finished_cars(self):
         first = self.tick
+        self._epoch += 1
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_advance_finished_cars(self.h, self._stream()))
             self.tick += 1
@@ -396,12 +428,14 @@ class TfxEngine(object):
         """(x, v, w) as NumPy [E,R,C] copies (w is zeros when it is not carried)."""
         ring = self.xv.cpu().numpy()
         x, v = ring[..., 0], ring[..., 1]
-        w = self.w.cpu().numpy() if self.w is not None else np.zeros_like(x)
+        w = self._ringw.cpu().numpy() if self.P == 3 else np.zeros_like(x)   # (exported with xv)
         return x, v, w
 
     # ---- bulk state import (tests, checkpoint restore) ----------------------------------------
     def load_state(self, x, v, leading, lastcar, w=None):
         """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
+        self._staging()
+        self._stage_epoch = self._epoch
         self._ring[..., 0].copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
         self._ring[..., 1].copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
         if self._ringw is not None and w is not None:

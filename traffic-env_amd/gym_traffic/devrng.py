@@ -27,6 +27,24 @@ def philox4x32(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def philox4x32_first(c0, c1, c2, c3, k0, k1):
+    """First output word of philox4x32 for an array of counters c0 (uint32 values in uint64 arrays)."""
+    import numpy as np
+    c0 = np.asarray(c0, np.uint64) & np.uint64(MASK)
+    c1 = np.full_like(c0, c1)
+    c2 = np.full_like(c0, c2)
+    c3 = np.full_like(c0, c3)
+    m = np.uint64(MASK)
+    s32 = np.uint64(32)
+    for _ in range(10):
+        p0 = np.uint64(M0) * c0
+        p1 = np.uint64(M1) * c2
+        c0, c1, c2, c3 = ((p1 >> s32) ^ c1 ^ np.uint64(k0)) & m, p1 & m, ((p0 >> s32) ^ c3 ^ np.uint64(k1)) & m, p0 & m
+        k0 = (k0 + W0) & MASK
+        k1 = (k1 + W1) & MASK
+    return c0
+
+
 def gap_table(cars_per_tick, tail=1e-12):
     """uint32 thresholds cdf[k] = floor(P(gap <= k) * 2^32), last entry 0xFFFFFFFF."""
     mean = 1.0 / float(cars_per_tick)
@@ -48,6 +66,7 @@ class PoissonMirror(object):
 
     def __init__(self, cars_per_tick, seed, n_entry, env_ids):
         self.cdf = [int(c) for c in gap_table(cars_per_tick)]
+        self.cdf_np = np.asarray(self.cdf[:-1], np.uint64)
         self.k0, self.k1 = int(seed) & MASK, (int(seed) >> 32) & MASK
         self.n_entry = int(n_entry)
         self.env_ids = [int(e) for e in env_ids]
@@ -73,12 +92,17 @@ class PoissonMirror(object):
                 self.gap[e] -= 1
                 continue
             while True:
-                c = self.car[e]
-                u = philox4x32((1 + 2 * c) & MASK, e, TAG_ROAD, 0, self.k0, self.k1)[0]
-                out[row, (u * self.n_entry) >> 32] += 1
-                self.car[e] = c + 1
-                g = self._gap(e, 2 + 2 * c)
-                if g > 0:
-                    self.gap[e] = g - 1
+                # 64 consecutive cars at a time, like the device's wavefront (bursts of thousands of
+                # cars per tick at cfg4's rate): every car up to the first non-zero gap arrives now
+                c = self.car[e] + np.arange(64, dtype=np.uint64)
+                ug = philox4x32_first(np.uint64(2) + np.uint64(2) * c, e, TAG_GAP, 0, self.k0, self.k1)
+                gaps = np.searchsorted(self.cdf_np, ug, side='right')     # k with cdf[k-1] <= u < cdf[k]
+                stop = np.nonzero(gaps > 0)[0]
+                f = int(stop[0]) if stop.size else 63
+                ur = philox4x32_first(np.uint64(1) + np.uint64(2) * c[:f + 1], e, TAG_ROAD, 0, self.k0, self.k1)
+                np.add.at(out[row], ((ur * np.uint64(self.n_entry)) >> np.uint64(32)).astype(np.int64), 1)
+                self.car[e] += f + 1
+                if stop.size:
+                    self.gap[e] = int(gaps[f]) - 1
                     break
         return out

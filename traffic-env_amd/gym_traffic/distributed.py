@@ -4,8 +4,9 @@ Envs share nothing (each reference TrafficEnv owns its arrays, traffic_env.py:36
 simply owns the contiguous env-id range `shard_range(total, k, world)`; per-env inputs are functions
 of the GLOBAL env id (spawner seeds, light-cycle offsets), which makes results independent of the
 sharding.  The only exchange is optional: `RolloutGather` collects (obs, reward, done) snapshots on
-rank 0 - a gather over RCCL/xGMI (backend "nccl") on a side stream so the next ticks overlap it, or
-over gloo on CPU tensors in tests.
+rank 0 - ONE gather per snapshot over RCCL/xGMI (backend "nccl") on a side stream so the next ticks
+overlap it, or over gloo on CPU tensors in tests.  Snapshots are double-buffered: starting snapshot
+k waits only for snapshot k-2 (the previous user of the same buffer), never for k-1.
 """
 import torch
 import torch.distributed as dist
@@ -19,60 +20,101 @@ def shard_range(total, rank, world):
 
 
 class RolloutGather(object):
+    """Snapshot layout (int32 words, one contiguous buffer per rank and per slot):
+        [ obs  n_max*obs_len | rewards (f32 bits) n_max*I | done  n_max ]
+    with n_max the largest shard, so every rank sends the same number of words."""
+
+    DEPTH = 2
+
     def __init__(self, n_local, obs_len, n_intersections, device, dst=0, group=None):
         self.dst, self.group = dst, group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        on = dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
         self.device = torch.device(device)
         # gloo cannot gather device tensors: rehearsals on one GPU (and CPU tests) stage through host
         # memory; with RCCL ("nccl") the snapshots stay on the device
-        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        backend = dist.get_backend(group) if on else "none"
         self.stage_dev = torch.device("cpu") if (backend == "gloo" and self.device.type == "cuda") else self.device
-        self.shapes = ((n_local, obs_len), (n_local, n_intersections), (n_local,))
-        self.dtypes = (torch.int32, torch.float32, torch.uint8)
-        # snapshots: obs/rewards are live buffers the next tick overwrites
-        self.snap = [torch.empty(s, dtype=t, device=self.stage_dev) for s, t in zip(self.shapes, self.dtypes)]
+        self.n, self.L, self.I = int(n_local), int(obs_len), int(n_intersections)
+        self.counts = [self.n]
+        if self.world > 1:
+            # shards may differ by one env: agree on the sizes once, on the host
+            sizes = [None] * self.world
+            dist.all_gather_object(sizes, self.n, group=group)
+            self.counts = [int(s) for s in sizes]
+        self.n_max = max(self.counts)
+        self.o_rew = self.n_max * self.L
+        self.o_done = self.o_rew + self.n_max * self.I
+        self.words = self.o_done + self.n_max
+        pin = self.stage_dev.type == "cpu" and self.device.type == "cuda"
+        self.snap = [self._buf(pin) for _ in range(self.DEPTH)]
         self.recv = None
         if self.rank == dst and self.world > 1:
-            self.recv = [[torch.empty(s, dtype=t, device=self.stage_dev) for _ in range(self.world)]
-                         for s, t in zip(self.shapes, self.dtypes)]
+            self.recv = [[self._buf(False) for _ in range(self.world)] for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
-        self.pending = []
+        self.pending = [None] * self.DEPTH
+        self.started = 0
+        self.collectives = 0          # gathers issued (one per snapshot)
+
+    def _buf(self, pin):
+        t = torch.zeros((self.words,), dtype=torch.int32, device=self.stage_dev)
+        return t.pin_memory() if pin else t
+
+    def _wait_slot(self, k):
+        w = self.pending[k]
+        if w is not None:
+            w.wait()
+            self.pending[k] = None
 
     def start(self, obs, rewards, done):
-        """Snapshot the three tensors and start gathering them to `dst`; returns immediately."""
-        self.wait()
+        """Snapshot the three tensors and start gathering them to `dst`; returns immediately.  Only
+        the gather that last used this snapshot's buffer (two starts ago) is waited for."""
+        k = self.started % self.DEPTH
+        self.started += 1
+        snap = self.snap[k]
+        n, L, I = self.n, self.L, self.I
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             ctx = torch.cuda.stream(self.side)
         else:
             ctx = _Null()
         with ctx:
-            for s, t in zip(self.snap, (obs, rewards, done)):
-                s.copy_(t, non_blocking=True)
+            self._wait_slot(k)        # (RCCL: orders the side stream after that gather; gloo: blocks)
+            snap[:n * L].view(n, L).copy_(obs, non_blocking=True)
+            snap[self.o_rew:self.o_rew + n * I].view(torch.float32).view(n, I).copy_(rewards, non_blocking=True)
+            snap[self.o_done:self.o_done + n].copy_(done, non_blocking=True)       # u8 -> i32
             if self.stage_dev.type == "cpu" and self.side is not None:
                 self.side.synchronize()            # host copies must have landed before gloo reads them
             if self.world > 1:
-                for k, s in enumerate(self.snap):
-                    self.pending.append(dist.gather(s, self.recv[k] if self.rank == self.dst else None,
-                                                    dst=self.dst, group=self.group, async_op=True))
+                self.pending[k] = dist.gather(snap, self.recv[k] if self.rank == self.dst else None,
+                                              dst=self.dst, group=self.group, async_op=True)
+                self.collectives += 1
 
     def wait(self):
-        """Block the host until the last started gather has landed (no-op if none)."""
-        for w in self.pending:
-            w.wait()
-        self.pending = []
+        """Block the host until every started gather has landed (no-op if none)."""
+        for k in range(self.DEPTH):
+            self._wait_slot(k)
         if self.side is not None:
             self.side.synchronize()
 
     def result(self):
-        """On dst: (obs [world*n, L], rewards [world*n, I], done [world*n]) in env-id order."""
+        """On dst: (obs [sum n, L], rewards [sum n, I], done [sum n]) of the LAST started snapshot, in
+        env-id order; None on the other ranks."""
         self.wait()
+        k = (self.started - 1) % self.DEPTH
         if self.world == 1:
-            return tuple(self.snap)
-        if self.rank != self.dst:
+            parts, counts = [self.snap[k]], [self.n]
+        elif self.rank != self.dst:
             return None
-        return tuple(torch.cat(parts, dim=0) for parts in self.recv)
+        else:
+            parts, counts = self.recv[k], self.counts
+        L, I = self.L, self.I
+        obs = torch.cat([p[:n * L].view(n, L) for p, n in zip(parts, counts)], dim=0)
+        rew = torch.cat([p[self.o_rew:self.o_rew + n * I].view(torch.float32).view(n, I)
+                         for p, n in zip(parts, counts)], dim=0)
+        done = torch.cat([p[self.o_done:self.o_done + n] for p, n in zip(parts, counts)], dim=0).to(torch.uint8)
+        return obs, rew, done
 
 
 class _Null(object):

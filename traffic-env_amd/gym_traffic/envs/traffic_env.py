@@ -58,9 +58,10 @@ class DeviceView(object):
     """NumPy-looking window on one env's slice of a device tensor: reads download, item
     assignment uploads (and lets the engine rebuild what it caches)."""
 
-    def __init__(self, tensor_fn, after_write=None, dtype=None):
+    def __init__(self, tensor_fn, after_write=None, dtype=None, before_write=None):
         self._t = tensor_fn
         self._after = after_write
+        self._before = before_write
         self._dtype = dtype
 
     def numpy(self):
@@ -76,9 +77,21 @@ class DeviceView(object):
 
     def __setitem__(self, idx, value):
         import torch
-        a = self._t().detach().cpu().numpy().copy()
-        a[idx] = value
-        self._t().copy_(torch.as_tensor(a))
+        if self._before:
+            self._before()
+        t = self._t()
+        whole = (isinstance(idx, slice) and idx == slice(None)) or idx is Ellipsis
+        if whole and np.ndim(value) == 0:
+            # `passed_dst[:] = False` (Remi, traffic_test.py:63) and the like: one device-side fill,
+            # no download / upload of the tensor
+            t.fill_(value)
+        elif whole:
+            t.copy_(torch.as_tensor(np.ascontiguousarray(np.broadcast_to(
+                np.asarray(value), tuple(t.shape)))).to(t.dtype))
+        else:
+            a = t.detach().cpu().numpy().copy()
+            a[idx] = value
+            t.copy_(torch.as_tensor(a))
         if self._after:
             self._after()
 
@@ -173,8 +186,10 @@ class TrafficEnv(gym.Env):
         eng = self.engine
         # [R, 3, C] = the reference's state[:, (xi, vi, wi), :]; a read assembles it from the device
         self.state = StateView(eng)
-        self.leading = DeviceView(lambda: eng.leading[0], eng.refresh)
-        self.lastcar = DeviceView(lambda: eng.lastcar[0], eng.refresh)
+        # ring semantics for `env.leading[i] = k`: the cars keep their SLOTS, so the slot image is
+        # exported under the old indices before the write and imported under the new ones after it
+        self.leading = DeviceView(lambda: eng.leading[0], eng.refresh, before_write=eng._export)
+        self.lastcar = DeviceView(lambda: eng.lastcar[0], eng.refresh, before_write=eng._export)
         self.waiting = DeviceView(lambda: eng.waiting[0])
         self.passed_dst = DeviceView(lambda: eng.passed_dst[0], dtype=np.bool_)
         self._spawn_counts = np.zeros((1, max(1, eng.n_entry)), np.int32)

@@ -62,7 +62,7 @@ class TrafficVecEnv(object):
         """Start a new episode in the envs that are done (default: the `done` flags of the last step
         or decision), leaving the others running; returns the mask that was reset."""
         eng = self.engine
-        mask = eng.done if done is None else done
+        mask = eng.done.clone() if done is None else done      # (reset_envs clears eng.done of those envs)
         if phase_init is None:
             phase_init = self._phase_rng.randint(2, size=(eng.E, eng.I)).astype(np.int32)
         eng.reset_envs(mask, phase_init)

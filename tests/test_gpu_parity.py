@@ -286,6 +286,47 @@ def test_random_states_vs_oracle(m, n, C, length, validate, sorted_x):
                 assert np.array_equal(eng.trip_times[k, :nt[k]].cpu().numpy(), orc.trip_times[k, :nt[k]])
 
 
+@pytest.mark.parametrize("variant", ["91", "92", "94", "98"])
+def test_streaming_move_kernels_on_random_states(variant, monkeypatch, car_layout):
+    """The one-wavefront-per-tile kernels (k_move_t, the default for launches that fill the chip, and
+    k_move_t2 with groups of 2 / 4 / 8 rows - the packed-pair arithmetic with its per-group domain
+    test) forced at test sizes, where the
+    launch heuristics would pick the four-waves-per-tile kernel: pathological ring states (cars past
+    the end, unsorted, NaN-producing zero gaps, huge speeds that leave the fast domain) and ordinary
+    traffic, bit-equal to the oracle."""
+    if car_layout != "transposed":
+        pytest.skip("transposed-layout kernels")
+    monkeypatch.setenv("TFX_MOVE_VARIANT", variant)
+    rng = np.random.RandomState(77 + int(variant))
+    for (m, n, C, length, E) in [(2, 2, 10, 60.0, 5), (3, 3, 34, 200.0, 40), (2, 3, 66, 400.0, 9), (2, 2, 130, 300.0, 3)]:
+        eng = engine_for(dict(m=m, n=n, length=length, capacity=C, rate=0.5), n_envs=E)
+        orc = oracle_like(eng)
+        for trial in range(3):
+            x, v, w, leading, lastcar = random_state(rng, E, eng.R, C, length, crowd=rng.choice([0.3, 0.8]),
+                                                     beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=bool(trial % 2))
+            if trial == 2:
+                # leave the fast domain on purpose: enormous and denormal speeds, exact-zero gap denominators
+                v[rng.rand(*v.shape) < 0.02] = 3e7
+                v[rng.rand(*v.shape) < 0.02] = 1e-30
+                pick = rng.rand(*x[:, :, 2:].shape) < 0.05          # follower exactly one car length behind:
+                x[:, :, 2:][pick] = (x[:, :, 1:-1] - np.float32(4.0))[pick]   # gap denominator = eps
+                np.put_along_axis(x, leading[:, :, None].astype(np.int64), np.inf, axis=2)   # (fake leaders stay at +inf)
+            phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+            elapsed = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
+            load_both(eng, orc, x, v, w, leading, lastcar, phase, elapsed)
+            eng.set_tick(60)
+            orc.steps[:] = 60
+            for t in range(8):
+                act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+                roads = [rng.choice(eng.entrypoints, size=rng.randint(0, 4)).tolist() for _ in range(E)]
+                eng.set_spawns(counts=counts(eng, roads))
+                eng.set_actions(act)
+                eng.step(1)
+                _, _, odone = orc.step(act, roads)
+                assert np.array_equal(eng.done.cpu().numpy(), odone), (variant, trial, t)
+                assert_same_state(eng, orc, "variant %s C=%d trial %d tick %d" % (variant, C, trial, t))
+
+
 def test_kernel_halves_vs_oracle():
     """tfx_move_cars and tfx_advance_finished_cars on their own (the numba-signature level of the
     boundary, traffic_env.py:187-191 and :117-120)."""

@@ -26,7 +26,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_LINES", "TFX_KINDS")}
+    keep = {k: os.environ.get(k) for k in ("TFX_LINES", "TFX_KINDS", "TFX_MOVE_VARIANT")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -49,8 +49,10 @@ def _run(rng, seed, LIMIT):
         spec = int(rng.choice([0, 0, 0b0001, 0b1010, 0b1110, 0b0110]))
         E = int(rng.choice([1, 2, 3, 9, 40, 130]))
         layout = str(rng.choice(["ring", "transposed", "transposed"]))
-        os.environ.pop("TFX_LINES", None); os.environ.pop("TFX_KINDS", None)
+        os.environ.pop("TFX_LINES", None); os.environ.pop("TFX_KINDS", None); os.environ.pop("TFX_MOVE_VARIANT", None)
         mode = rng.randint(3)
+        mv = int(rng.choice([0, 0, 91, 94, 98]))      # launch heuristics | streaming kernels forced at any size
+        if layout == "transposed" and mv: os.environ["TFX_MOVE_VARIANT"] = str(mv)
         if layout == "transposed" and not val and mode == 1: os.environ["TFX_LINES"] = "1"
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
@@ -92,7 +94,7 @@ def _run(rng, seed, LIMIT):
                               "next ld/lc", (ldh[kk, nx], lch[kk, nx]) if nx >= 0 else None,
                               "phase/elapsed", eng.obs[kk, 2*eng.r + e % eng.I].item() if e < eng.r else None, eng.obs[kk, 2*eng.r + eng.I + e % eng.I].item() if e < eng.r else None,
                               "next tail gpu/orc", (st[0][kk][nx, lch[kk, nx]], orc.x[kk][nx, orc.lastcar[kk, nx]]) if nx >= 0 else None)
-            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d) tick %d" % (n, m, nn, C, E, layout, val, mode, t))
+            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, t))
         if val:
             nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n
             for kk in range(E): assert np.array_equal(eng.trip_times[kk, :min(nt[kk], eng.trip_cap)].cpu().numpy(), orc.trip_times[kk, :min(nt[kk], eng.trip_cap)]), n

@@ -30,6 +30,7 @@ struct Dev {
   float two_sab, eps, thresh, near_end, ovf_pen;
   float r_two_sab, r_v0;  // correctly rounded reciprocals of the two constant divisors
   int fastdiv;            // the reciprocal form of those divisions was verified exact (div_selftest)
+  int fastmax;            // v_max_f32 orders +0 above -0 in either operand order (k_max_selftest)
   // caller-owned state
   float2 *xv;  // [E][R][C] (x, v) per ring slot
   float *w;    // [E][R][C] spawn tick per ring slot, or nullptr

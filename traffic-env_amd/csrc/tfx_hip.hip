@@ -22,6 +22,7 @@
 #include "tfx_move_generic.hpp"
 #include "tfx_move_dma.hpp"
 #include "tfx_move_t.hpp"
+#include "tfx_move_t2.hpp"
 #include "tfx_move_ts.hpp"
 #include "tfx_line.hpp"
 #include "tfx_advance.hpp"
@@ -261,7 +262,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   // 0.083; no gain at cfg2 x 64 (1088) and a loss at cfg1 x 1024 (1280): there the redundant road
   // prologues outweigh the shorter walks
   const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
-  if (pvar == 90 || (pvar == 0 && tiles <= split_below)) {
+  if (pvar == 90 || (tiles <= split_below && (pvar == 0 || (pvar >= 100 && pvar < 110)))) {
     auto gs = [&](auto kern) {
       if (h->grid_move == 0) h->grid_move = (int)(tiles < (long)h->n_cu * 8 ? tiles : (long)h->n_cu * 8);
       if (h->size_only) return (int)TFX_OK;
@@ -282,6 +283,13 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     return gs(k_move_ts<64>);
   }
   if (h->d.w) return go(k_move_t<4, 3, false, true>);  // validate mode: the spawn-tick plane travels along
+  // k_move_t2 (tfx_move_t2.hpp): packed-pair arithmetic, one domain test per group of 2 / 4 / 8 rows -
+  // a third fewer vector instructions, bit-identical, and measured 2-3 % SLOWER than k_move_t at cfg2
+  // (same box: 0.670 / 0.664 / 0.678 ms against 0.651): the launch is not VALU-limited.
+  // Kept as A/B points (102 / 104 / 108; 92 / 94 / 98 = the same, never the four-waves-per-tile kernel).
+  if (pvar == 102 || pvar == 92) return go(k_move_t2<2>);
+  if (pvar == 104 || pvar == 94) return go(k_move_t2<4>);
+  if (pvar == 108 || pvar == 98) return go(k_move_t2<8>);
   // A/B points kept from the tuning runs
   if (pvar == 51) return go(k_move_t<1, 3>);
   if (pvar == 52) return go(k_move_t<2, 3>);
@@ -614,6 +622,13 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
       (void)hipMemset(bad, 0, sizeof nbad);
       h->div_mismatches = nbad;
     }
+  }
+  {
+    unsigned *bad = (unsigned *)(base + o_misc);  // (cleared again above)
+    hipLaunchKernelGGL(k_max_selftest, dim3(1), dim3(1), 0, 0, bad, 0.0f, -0.0f);
+    unsigned nbad = 1;
+    if (hipMemcpy(&nbad, bad, sizeof nbad, hipMemcpyDeviceToHost) == hipSuccess && nbad == 0) d.fastmax = 1;
+    (void)hipMemset(bad, 0, 8);
   }
   d.action_mode = TFX_ACTION_CYCLE;
   d.action_period = 20;

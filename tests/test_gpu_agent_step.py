@@ -13,6 +13,15 @@ from gym_traffic import workload as wl  # noqa: E402
 from gym_traffic.core import TfxEngine  # noqa: E402
 
 
+@pytest.fixture(params=["resident", "pertick"], autouse=True)
+def step_path(request, monkeypatch):
+    """Both forms of the fused decision: every tick in one LDS-resident launch (k_res, 3 envs per
+    workgroup) and the captured sequence of per-tick kernels."""
+    monkeypatch.setenv("TFX_RESIDENT", "1" if request.param == "resident" else "0")
+    monkeypatch.setenv("TFX_RES_EPB", "3")
+    yield request.param
+
+
 def emulate_agent_step(orcs, tick0, action, entry, n_ticks, remi, period):
     """Repeater._step + Remi._step per env on single-env oracles; returns (aobs, areward, adone)."""
     E = len(orcs)

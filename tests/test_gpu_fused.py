@@ -1,8 +1,9 @@
-"""k_line (opt-in, TFX_LINES=1): tfx_step(n >= 2) on the transposed layout runs its ticks fused - cars
-resident in LDS, street lines inside a wavefront - and must be bit-identical to the tick-by-tick path and to the
-oracle: pathological ring states (wrapped, full, empty, unsorted, cars more than a road length past
-the end so that handed-off cars cascade through several roads in one tick), per-tick action and
-spawn buffers, the on-device rules, rectangular grids, every capacity class."""
+"""k_res (tfx_resident.hpp): envs that fit a compute unit's LDS run all the ticks of a tfx_step /
+tfx_agent_step call in one launch, the cars resident on chip.  It must be bit-identical to the
+tick-by-tick kernels and to the oracle: pathological ring states (wrapped, full, empty, unsorted, cars
+more than a road length past the end so that handed-off cars cascade through several roads in one
+tick), per-tick action and spawn buffers, the on-device rules, rectangular grids, every capacity
+class, both global car layouts, one or several envs per workgroup."""
 import numpy as np
 import pytest
 
@@ -20,17 +21,29 @@ from gym_traffic import workload as wl  # noqa: E402
 import os  # noqa: E402
 
 
-def fused_engine(E, **cfg):
-    old = os.environ.get("TFX_LINES")
-    os.environ["TFX_LINES"] = "1"           # read by tfx_create: line-ordered slots, k_line allowed
+def engine_with(env, E, layout="transposed", planes=2, **cfg):
+    keep = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)                  # read when the engine binds its buffers
     try:
-        eng = TfxEngine(n_envs=E, planes=2, layout="transposed", **cfg)
+        eng = TfxEngine(n_envs=E, planes=planes, layout=layout, **cfg)
     finally:
-        if old is None:
-            del os.environ["TFX_LINES"]
-        else:
-            os.environ["TFX_LINES"] = old
+        for k, v in keep.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return eng
+
+
+def fused_engine(E, epb=2, **cfg):
+    eng = engine_with({"TFX_RESIDENT": "1", "TFX_RES_EPB": str(epb)}, E, **cfg)
     assert eng.fused_ticks() == (0, True)
+    return eng
+
+
+def pertick_engine(E, **cfg):
+    eng = engine_with({"TFX_RESIDENT": "0"}, E, **cfg)
+    assert eng.fused_ticks() == (0, False)
     return eng
 
 
@@ -38,10 +51,12 @@ def fused_engine(E, **cfg):
                                           (2, 3, 66, 400.0), (5, 3, 12, 80.0), (1, 1, 6, 50.0),
                                           (2, 2, 130, 800.0)])
 @pytest.mark.parametrize("sorted_x", [True, False])
-def test_fused_random_states_vs_oracle(m, n, C, length, sorted_x):
+@pytest.mark.parametrize("layout", ["transposed", "ring"])
+def test_fused_random_states_vs_oracle(m, n, C, length, sorted_x, layout):
     rng = np.random.RandomState(4321 + C + int(sorted_x))
     E, T = 5, 7
-    eng = fused_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    eng = fused_engine(E, epb=1 + C % 3, layout=layout, planes=3 if layout == "ring" else 2, m=m, n=n,
+                       length=length, capacity=C, rate=0.5)
     orc = oracle_like(eng)
     ran = 0
     for trial in range(5):
@@ -72,10 +87,9 @@ def test_fused_equals_tick_by_tick_on_device_rules():
     60 single ticks == the same with fusing disabled; counters and done flags included."""
     E, T = 9, 60
     cfg = dict(m=4, n=4, length=200.0, capacity=34, rate=0.5)
-    a = fused_engine(E, **cfg)
-    b = fused_engine(E, **cfg)
-    c = TfxEngine(n_envs=E, planes=2, layout="transposed", **cfg)     # default: road-id slots, per-tick kernels
-    assert c.fused_ticks() == (0, False)
+    a = fused_engine(E, epb=4, **cfg)
+    b = fused_engine(E, epb=1, **cfg)
+    c = pertick_engine(E, **cfg)
     x, v, leading, lastcar = wl.prefill_one_env(4, 4, 200.0, 34, 24, 8.0)
     for eng in (a, b, c):
         eng.reset(np.zeros((E, eng.I), np.int32))
@@ -89,7 +103,7 @@ def test_fused_equals_tick_by_tick_on_device_rules():
     for _ in range(T):
         b.step(1)
     c.step(T)
-    assert a.fused_ticks()[0] == T and b.fused_ticks()[0] == 0 and c.fused_ticks()[0] == 0
+    assert a.fused_ticks()[0] == T and b.fused_ticks()[0] == T and c.fused_ticks()[0] == 0
     assert_engines_equal(a, b)
     assert_engines_equal(c, b)
     assert a.vehicle_updates() == b.vehicle_updates() == c.vehicle_updates() > 0
@@ -121,4 +135,4 @@ def test_fused_odd_chunks_and_golden_ints(golden_cache):
         assert np.array_equal(eng.lastcar[0].cpu().numpy(), g["lastcar"][t])
         assert np.array_equal(eng.obs[0].cpu().numpy(), g["obs"][t])
         assert np.array_equal(eng.rewards[0].cpu().numpy(), g["rewards"][t])
-    assert t == 120 and eng.fused_ticks()[0] == 118
+    assert t == 120 and eng.fused_ticks()[0] == 120

@@ -34,6 +34,19 @@ def car_layout(request):
     _LAYOUT[0] = "ring"
 
 
+# ... and through both step paths: the LDS-resident multi-tick kernel k_res (what small envs get by
+# default, packing 3 envs per workgroup so wavefronts straddle env boundaries) and the per-tick
+# streaming kernels (TFX_RESIDENT=0: what big envs get)
+@pytest.fixture(params=["resident", "pertick"], autouse=True)
+def step_path(request, monkeypatch):
+    if request.param == "resident":
+        monkeypatch.setenv("TFX_RESIDENT", "1")
+        monkeypatch.setenv("TFX_RES_EPB", "3")
+    else:
+        monkeypatch.setenv("TFX_RESIDENT", "0")
+    yield request.param
+
+
 def engine_for(g_or_cfg, n_envs=1, **kw):
     from gym_traffic.core import TfxEngine
     if isinstance(g_or_cfg, dict):
@@ -287,15 +300,15 @@ def test_random_states_vs_oracle(m, n, C, length, validate, sorted_x):
 
 
 @pytest.mark.parametrize("variant", ["91", "92", "94", "98"])
-def test_streaming_move_kernels_on_random_states(variant, monkeypatch, car_layout):
+def test_streaming_move_kernels_on_random_states(variant, monkeypatch, car_layout, step_path):
     """The one-wavefront-per-tile kernels (k_move_t, the default for launches that fill the chip, and
     k_move_t2 with groups of 2 / 4 / 8 rows - the packed-pair arithmetic with its per-group domain
     test) forced at test sizes, where the
     launch heuristics would pick the four-waves-per-tile kernel: pathological ring states (cars past
     the end, unsorted, NaN-producing zero gaps, huge speeds that leave the fast domain) and ordinary
     traffic, bit-equal to the oracle."""
-    if car_layout != "transposed":
-        pytest.skip("transposed-layout kernels")
+    if car_layout != "transposed" or step_path != "pertick":
+        pytest.skip("transposed-layout per-tick kernels")
     monkeypatch.setenv("TFX_MOVE_VARIANT", variant)
     rng = np.random.RandomState(77 + int(variant))
     for (m, n, C, length, E) in [(2, 2, 10, 60.0, 5), (3, 3, 34, 200.0, 40), (2, 3, 66, 400.0, 9), (2, 2, 130, 300.0, 3)]:

@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP path against the CPU oracle, for as long as FUZZ_SECS allows
 (default 420 s): random grid shape, capacity, road length, rate, learn_switch, validate, entry sides,
-batch size, car layout (ring / transposed, line- and id-ordered slots), pathological or reset start
+batch size, car layout (ring / transposed), step path (LDS-resident k_res with 1-5 envs per workgroup / per-tick kernels), pathological or reset start
 states, arrival density, uneven multi-tick calls.  Every call must leave the engine bit-equal to the
 oracle.  The RNG state at the start of the current case is kept in gpurun_out/fuzz_case_start.pkl:
 
@@ -26,7 +26,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_LINES", "TFX_KINDS", "TFX_MOVE_VARIANT")}
+    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_KINDS", "TFX_MOVE_VARIANT")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -49,11 +49,12 @@ def _run(rng, seed, LIMIT):
         spec = int(rng.choice([0, 0, 0b0001, 0b1010, 0b1110, 0b0110]))
         E = int(rng.choice([1, 2, 3, 9, 40, 130]))
         layout = str(rng.choice(["ring", "transposed", "transposed"]))
-        os.environ.pop("TFX_LINES", None); os.environ.pop("TFX_KINDS", None); os.environ.pop("TFX_MOVE_VARIANT", None)
+        os.environ.pop("TFX_KINDS", None); os.environ.pop("TFX_MOVE_VARIANT", None)
         mode = rng.randint(3)
         mv = int(rng.choice([0, 0, 91, 94, 98]))      # launch heuristics | streaming kernels forced at any size
         if layout == "transposed" and mv: os.environ["TFX_MOVE_VARIANT"] = str(mv)
-        if layout == "transposed" and not val and mode == 1: os.environ["TFX_LINES"] = "1"
+        os.environ["TFX_RESIDENT"] = "1" if mode == 1 else "0"      # LDS-resident multi-tick kernel | per-tick kernels
+        os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
         eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)

@@ -45,11 +45,9 @@ struct Dev {
   // handle-owned tables + scratch
   const int *nexts, *pred, *entry_idx;
   // transposed layout: road e of an env lives in storage slot road_slot[e] (tile = slot / 64, lane =
-  // slot % 64, G tiles per env); slot_road is the inverse (-1 = padding lane).  With `lines` set the
-  // slots follow the street lines (entry road -> ... -> exit road on consecutive lanes, whole lines
-  // per tile), which is what lets k_line run many ticks of a tile without leaving the wavefront.
+  // slot % 64, G tiles per env); slot_road is the inverse (-1 = padding lane)
   const int *road_slot, *slot_road;
-  int G, lines;
+  int G;
   int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T and in the outbox: >= C - 2
   int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows, bits of post-move tail x, live cars}
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this

@@ -24,7 +24,7 @@
 #include "tfx_move_t.hpp"
 #include "tfx_move_t2.hpp"
 #include "tfx_move_ts.hpp"
-#include "tfx_line.hpp"
+#include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_misc.hpp"
 
@@ -62,8 +62,11 @@ struct tfx_handle_s {
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
   int tiles_per_env = 0;      // G: 64-slot tiles one env occupies in the transposed layout
-  bool lines = false;         // slots follow the street lines (k_line can fuse ticks)
-  int fuse_ticks = 10;        // ticks one k_line launch runs (TFX_FUSE_TICKS; 0/1 = never fuse)
+  // k_res (tfx_resident.hpp): whole envs resident in LDS for all the ticks of a call
+  int res_epb = 0;            // envs per workgroup; 0 = the envs do not fit / disabled (TFX_RESIDENT=0)
+  int res_threads = 0;
+  size_t res_lds = 0;
+  int res_min_ticks = 1;      // calls shorter than this take the per-tick kernels (TFX_RES_MIN_TICKS)
   void *dev_scratch = nullptr;
   int32_t action_per_tick = 0, spawn_per_tick = 0;
   // optional per-kernel timing with HIP events on the launch stream (tfx_profile)
@@ -71,9 +74,7 @@ struct tfx_handle_s {
   int ev_ticks = 0, ev_used = 0;
   std::vector<int> ev_weight;  // ticks the i-th timed entry covers (1, or the ticks of a fused launch)
   bool prof = false;
-  long long fused_ticks = 0;   // ticks run by k_line since tfx_create
-  int grid_line = 0;           // k_line: blocks resident at once
-  size_t line_lds = 0;
+  long long fused_ticks = 0;   // ticks run by k_res since tfx_create
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
   size_t move_lds = 0;
@@ -135,57 +136,26 @@ void build_tables(tfx_handle_s *h) {
   for (size_t j = 0; j < h->h_entry.size(); ++j) h->h_entry_idx[h->h_entry[j]] = (int)j;
 }
 
-// Storage slots of the transposed layout.  A street line = an entry road followed through `nexts`
-// to its exit road (roadgraph.py:54-64: cars never turn, so lines share nothing but the lights).
-// With TFX_LINES=1 and every line fitting a wavefront, whole lines are packed into each 64-slot
-// tile, consecutive roads of a line on consecutive lanes; otherwise slots are road ids.
+// Storage slots of the transposed layout: road e of an env lives in slot road_slot[e].
+// Roads of a kind behave alike - entry roads queue the arrivals, exit roads only drain - and a
+// wavefront walks its tile as far as the tile's LONGEST road, so kinds are not mixed: interior
+// train roads in id order (runs of consecutive ids: the per-road words still coalesce), then the
+// entry roads, then the exit roads.  At cfg2 that is 15 + 1 + 1 tiles instead of ten tiles that
+// each carry a few long entry roads (TFX_KINDS=0: plain id order).
 void build_slots(tfx_handle_s *h) {
   const int R = (int)h->h_nexts.size(), r = 4 * h->cfg.m * h->cfg.n;
-  std::vector<std::vector<int>> lines;
-  std::vector<char> seen(R, 0);
-  for (int e = 0; e < r; ++e) {
-    if (h->h_pred[e] >= 0) continue;
-    lines.emplace_back();
-    for (int q = e; q >= 0; q = h->h_nexts[q]) {
-      lines.back().push_back(q);
-      seen[q] = 1;
-    }
-  }
-  size_t longest = 0;
-  bool all = true;
-  for (auto &l : lines) longest = l.size() > longest ? l.size() : longest;
-  for (int e = 0; e < R; ++e) all = all && seen[e];
-  // Opt-in (TFX_LINES=1): measured at cfg2 the fused kernel this order enables is LDS-capacity bound
-  // (4 wavefronts per CU, 1.7 ms per tick against 0.71 ms for the streaming kernels) and the
-  // per-road words of column lines stop coalescing in the per-tick kernels.
-  const char *lv = getenv("TFX_LINES");
-  h->lines = all && longest >= 1 && longest <= 64 && lv && atoi(lv) != 0;
-  if (h->lines) {
-    const int per_tile = 64 / (int)longest;
-    h->tiles_per_env = ((int)lines.size() + per_tile - 1) / per_tile;
-    h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
-    for (size_t li = 0; li < lines.size(); ++li)
-      for (size_t q = 0; q < lines[li].size(); ++q)
-        h->h_slot_road[(li / per_tile) * 64 + (li % per_tile) * longest + q] = lines[li][q];
+  const char *kv = getenv("TFX_KINDS");
+  std::vector<int> order;
+  if (!(kv && atoi(kv) == 0)) {
+    for (int e = 0; e < r; ++e) if (h->h_pred[e] >= 0) order.push_back(e);
+    for (int e = 0; e < r; ++e) if (h->h_pred[e] < 0) order.push_back(e);
+    for (int e = r; e < R; ++e) order.push_back(e);
   } else {
-    // Roads of a kind behave alike - entry roads queue the arrivals, exit roads only drain - and a
-    // wavefront walks its tile as far as the tile's LONGEST road, so kinds are not mixed: interior
-    // train roads in id order (runs of consecutive ids: the per-road words still coalesce), then the
-    // entry roads, then the exit roads.  At cfg2 that is 15 + 1 + 1 tiles instead of ten tiles that
-    // each carry a few long entry roads (TFX_KINDS=0: plain id order).
-    const char *kv = getenv("TFX_KINDS");
-    std::vector<int> order;
-    if (!(kv && atoi(kv) == 0)) {
-      for (int e = 0; e < r; ++e) if (h->h_pred[e] >= 0) order.push_back(e);
-      for (int e = 0; e < r; ++e) if (h->h_pred[e] < 0) order.push_back(e);
-      for (int e = r; e < R; ++e) order.push_back(e);
-    } else {
-      for (int e = 0; e < R; ++e) order.push_back(e);
-    }
-    h->tiles_per_env = (R + 63) / 64;
-    h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
-    for (int s = 0; s < R; ++s) h->h_slot_road[s] = order[s];
+    for (int e = 0; e < R; ++e) order.push_back(e);
   }
+  h->tiles_per_env = (R + 63) / 64;
+  h->h_slot_road.assign((size_t)h->tiles_per_env * 64, -1);
+  for (int s = 0; s < R; ++s) h->h_slot_road[s] = order[s];
   h->h_road_slot.assign(R, -1);
   for (size_t s = 0; s < h->h_slot_road.size(); ++s)
     if (h->h_slot_road[s] >= 0) h->h_road_slot[h->h_slot_road[s]] = (int)s;
@@ -358,35 +328,58 @@ int launch_inputs(tfx_handle h, hipStream_t st) {
   return TFX_OK;
 }
 
-// k_line: LDS ring rows per road (power of two >= C - 2) and the launch
-int line_rows(tfx_handle h) {
-  int rows = 1;
-  while (rows < h->d.C - 2) rows <<= 1;
-  return rows;
-}
-size_t line_lds_bytes(tfx_handle h) { return (size_t)line_rows(h) * 64 * sizeof(float2); }
-
-int launch_line(tfx_handle h, int tidx0, int n_ticks, hipStream_t st, hipEvent_t *ev = nullptr) {
+// k_res: how many envs a workgroup takes (0 = not applicable).  Limits: one lane per road and at most
+// 1024 lanes; the rings of the workgroup's envs in the LDS a workgroup may have (asked from the
+// runtime with hipFuncSetAttribute: 160 KB per CU on gfx950).
+template <bool W>
+int res_configure(tfx_handle h) {
   const Dev &d = h->d;
-  if (h->grid_line == 0) {
-    h->line_lds = line_lds_bytes(h);
-    if (h->line_lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void *)k_line, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->line_lds));
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_line, 64, h->line_lds) != hipSuccess || per_cu < 1)
-      per_cu = 1;
-    const long tiles = (long)d.E * d.G;
-    long g = (long)h->n_cu * per_cu;
-    if (const char *gm = getenv("TFX_LINE_GRID")) g = (long)h->n_cu * atoi(gm);
-    h->grid_line = (int)(g > tiles ? tiles : (g < 1 ? 1 : g));
+  h->res_epb = 0;
+  if (const char *rv = getenv("TFX_RESIDENT")) if (atoi(rv) == 0) return TFX_OK;
+  if (const char *mt = getenv("TFX_RES_MIN_TICKS")) h->res_min_ticks = atoi(mt);
+  if (d.R > 1024) return TFX_OK;
+  const size_t lds_cap = 160 * 1024;
+  int want = (d.E + h->n_cu - 1) / h->n_cu;  // spread the envs over the chip first
+  if (const char *ev = getenv("TFX_RES_EPB")) want = atoi(ev);
+  if (want < 1) want = 1;
+  if (want > d.E) want = d.E;
+  int epb = 0, threads = 0;
+  size_t lds = 0;
+  for (int k = 1; k <= want; ++k) {
+    const int th = (k * d.R + 63) / 64 * 64;
+    const size_t b = res_lds_bytes(th, d.C, k, d.I, W);
+    if (th > 1024 || b > lds_cap) break;
+    epb = k; threads = th; lds = b;
   }
-  // rewards[:] = 0 (:233): the last tick's overflow penalties are added by the road lanes
-  HIPCHK(hipMemsetAsync(d.rewards, 0, (size_t)d.E * d.I * sizeof(float), st));
-  if (ev) HIPCHK(hipEventRecord(ev[0], st));
-  hipLaunchKernelGGL(k_line, dim3(h->grid_line), dim3(64), h->line_lds, st, d, tidx0, n_ticks, line_rows(h) - 1);
-  HIPCHK(hipGetLastError());
-  if (ev) HIPCHK(hipEventRecord(ev[1], st));
-  hipLaunchKernelGGL(k_line_lights, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d, tidx0, n_ticks);
+  if (epb == 0) return TFX_OK;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<W>)),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return TFX_OK;  // the runtime does not grant that much LDS: per-tick kernels
+  }
+  h->res_epb = epb;
+  h->res_threads = threads;
+  h->res_lds = lds;
+  return TFX_OK;
+}
+
+// the resident kernel serves a call when the envs fit, trip times are not recorded (their order is the
+// serial loop's) and the arrivals do not come from the on-device Poisson stream (a per-tick producer)
+bool res_usable(tfx_handle h, int n_ticks) {
+  return h->res_epb > 0 && !h->poisson && !h->d.validate && n_ticks >= h->res_min_ticks;
+}
+
+int launch_res(tfx_handle h, int n_ticks, hipStream_t st) {
+  const Dev &d = h->d;
+  ResArgs a;
+  a.epb = h->res_epb;
+  a.n_ticks = n_ticks;
+  a.greedy_spacing = h->greedy ? h->greedy_spacing : 0;
+  a.greedy_act = h->dev_greedy;
+  const int grid = (d.E + h->res_epb - 1) / h->res_epb;
+  if (d.w) hipLaunchKernelGGL(k_res<true>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
+  else hipLaunchKernelGGL(k_res<false>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, d, n_ticks);
   HIPCHK(hipGetLastError());
@@ -416,10 +409,15 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.agent_mode = 1;
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
-  for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
-    rc = launch_inputs(h, st);
-    if (rc == TFX_OK) rc = launch_move(h, t, st);
-    if (rc == TFX_OK) rc = launch_advance(h, t, st);
+  if (res_usable(h, n_ticks)) {
+    rc = launch_res(h, n_ticks, st);  // every tick of the decision in one launch, the cars in LDS
+    if (rc == TFX_OK) h->fused_ticks += n_ticks;
+  } else {
+    for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
+      rc = launch_inputs(h, st);
+      if (rc == TFX_OK) rc = launch_move(h, t, st);
+      if (rc == TFX_OK) rc = launch_advance(h, t, st);
+    }
   }
   d.agent_mode = keep_mode;
   d.accum_rewards = keep_acc;
@@ -465,7 +463,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     if (h->ag_exec) { (void)hipGraphExecDestroy(h->ag_exec); h->ag_exec = nullptr; }
     if (h->ag_graph) { (void)hipGraphDestroy(h->ag_graph); h->ag_graph = nullptr; }
     if (!h->ag_stream) HIPCHK(hipStreamCreateWithFlags(&h->ag_stream, hipStreamNonBlocking));
-    if (h->grid_move == 0) {  // size the move grid outside the capture (occupancy queries)
+    if (h->grid_move == 0 && !res_usable(h, n_ticks)) {  // size the move grid outside the capture (occupancy queries)
       if (int rc = launch_move_probe(h)) return rc;
     }
     HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
@@ -506,7 +504,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   h->cfg = *cfg;
   build_tables(h);
   build_slots(h);
-  if (const char *ft = getenv("TFX_FUSE_TICKS")) h->fuse_ticks = atoi(ft);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   int dev = 0;
@@ -568,7 +565,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.road_slot = h->dev_tables + 3 * R;
   d.slot_road = h->dev_tables + 4 * R;
   d.G = h->tiles_per_env;
-  d.lines = h->lines ? 1 : 0;
 
   // scratch
   const size_t ER = (size_t)d.E * R;
@@ -689,7 +685,7 @@ int tfx_bind_buffers(tfx_handle h, const tfx_buffers *b) {
   d.trip_cap = b->trip_cap;
   h->bound = true;
   ++h->input_gen;
-  return TFX_OK;
+  return d.w ? res_configure<true>(h) : res_configure<false>(h);
 }
 
 int tfx_reset(tfx_handle h, const int32_t *phase_init, void *stream) {
@@ -809,24 +805,24 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (n_ticks < 0) return fail(TFX_EINVAL, "n_ticks < 0");
   hipStream_t st = (hipStream_t)stream;
-  // whole street lines per wavefront, inputs that do not depend on the cars: fuse ticks in k_line
-  const bool fuse = h->lines && h->d.layout == 1 && !h->poisson && !h->greedy && !h->d.validate &&
-                    !h->d.agent_mode && h->fuse_ticks >= 2 && line_lds_bytes(h) <= 160 * 1024;
+  // envs that fit a compute unit's LDS: all the ticks of the call in one launch (tfx_resident.hpp)
+  if (n_ticks > 0 && res_usable(h, n_ticks)) {
+    const bool timed = h->prof && h->ev_used < h->ev_ticks;
+    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(e[0], st));
+    if (int rc = launch_res(h, n_ticks, st)) return rc;
+    h->fused_ticks += n_ticks;
+    if (timed) {
+      HIPCHK(hipEventRecord(e[1], st));
+      HIPCHK(hipEventRecord(e[2], st));
+      h->ev_weight[h->ev_used] = n_ticks;
+      ++h->ev_used;
+    }
+    return TFX_OK;
+  }
   for (int t = 0; t < n_ticks; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
-    const int chunk = n_ticks - t < h->fuse_ticks ? n_ticks - t : h->fuse_ticks;
-    if (fuse && chunk >= 2) {
-      if (int rc = launch_line(h, t, chunk, st, e)) return rc;
-      h->fused_ticks += chunk;
-      if (timed) {
-        HIPCHK(hipEventRecord(e[2], st));
-        h->ev_weight[h->ev_used] = chunk;
-        ++h->ev_used;
-      }
-      t += chunk - 1;
-      continue;
-    }
     if (int rc = launch_inputs(h, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[0], st));
     if (int rc = launch_move(h, t, st)) return rc;
@@ -987,7 +983,7 @@ int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches) {
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->fused_ticks;
-  if (capable) *capable = (h->lines && h->d.layout == 1 && h->fuse_ticks >= 2) ? 1 : 0;
+  if (capable) *capable = h->res_epb > 0 ? 1 : 0;
   return TFX_OK;
 }
 

@@ -1,0 +1,441 @@
+// tfx_resident.hpp - k_res: MANY ticks of the env step in ONE launch for envs small enough to live
+// in a compute unit's LDS (cfg0, cfg1, the reference's own 3x3 default: R * (C-1) * 8 bytes per env).
+//
+// The per-tick kernels stream every car through HBM twice per tick and pay two launches per tick;
+// for small grids that is all latency (round 1: cfg1 x 1024 envs at 0.18 of the HBM roofline, 38 us
+// per tick of which the cars need 3).  Here a workgroup owns `epb` whole envs for the whole call:
+//   * one lane per road (lanes = epb * R, packed across env boundaries so wavefronts stay full);
+//   * the cars sit in LDS in the REFERENCE's ring layout - ring[slot][lane], slots 1..C-1, the same
+//     leading / lastcar indices as traffic_env.py - so a tick moves no car that did not move: the IDM
+//     walk (k_move_t's lane-per-road chain: the leader of car k is the lane's previous car, OLD
+//     values, Jacobi) rewrites slots in place, pops advance `leading`, pushes advance `lastcar`;
+//   * a tick is: lights + spawns + walk | barrier | handoff | barrier.  The handoff is the pull form
+//     of tfx_advance.hpp (each road takes the cars its unique predecessor popped, under the
+//     reference's road-order rule) in two phases - every lane first copies its predecessor's popped
+//     cars to registers, barrier, then pushes them onto its own ring - which makes it exact for any
+//     number of pops and any ring fill (a push can only overwrite a popped car that was copied in
+//     the same or an earlier round).  Only a car that leaves TWO roads in one tick sends its env
+//     through the literal serial loop (one lane, on the LDS image);
+//   * the agent step's `if done: break` (traffic_test.py:55) is a per-env flag in LDS: the lanes of
+//     an env that overflowed idle through the remaining ticks of the call;
+//   * HBM is touched at the start (cars, indices, light words) and at the end (the same, plus obs,
+//     rewards, waiting, passed_dst); per-tick inputs (actions, arrival counts) are a few words.
+// Arithmetic, ring indices, counters: bit-identical to the per-tick kernels and the oracle
+// (tests/test_gpu_fused.py runs every case through both).
+#pragma once
+#include "tfx_common.hpp"
+#include "tfx_move_t.hpp"
+
+namespace tfx {
+
+struct ResArgs {
+  int epb;             // envs per workgroup
+  int n_ticks;
+  int greedy_spacing;  // > 0: the greedy controller decides in the kernel (algorithms/greedy.py:14-16)
+  int *greedy_act;     // [E][I] held greedy actions (in/out)
+};
+
+constexpr int RES_KH = 2;  // popped cars copied per handoff round
+
+// bytes of dynamic LDS for T lanes
+__host__ __device__ inline size_t res_lds_bytes(int T, int C, int epb, int I, bool W) {
+  const size_t ns = (size_t)(C - 1);
+  size_t b = ns * T * sizeof(float2);
+  if (W) b += ns * T * sizeof(float);
+  b += (size_t)T * 8 * 4;                // ld, lc, kpop, cnt, tail, passed, ovf, ovfsp
+  b += (size_t)epb * I * (2 * 8 + 4 + 4 + 4);  // light[2], rew, pdst, act
+  b += (size_t)epb * 2 * 4 + 16;         // ovftick, fartick, maxpop[2]
+  return (b + 15) & ~(size_t)15;
+}
+
+template <bool W>
+__global__ __launch_bounds__(1024) void k_res(const Dev d, const ResArgs a) {
+  extern __shared__ __align__(16) unsigned char res_smem[];
+  const int T = blockDim.x, C = d.C, NS = C - 1, R = d.R, I = d.I;
+  const int epb = a.epb;
+  float2 *ring = reinterpret_cast<float2 *>(res_smem);
+  float *ringw = reinterpret_cast<float *>(ring + (size_t)NS * T);
+  int *s_ld = reinterpret_cast<int *>(W ? (ringw + (size_t)NS * T) : ringw);
+  int *s_lc = s_ld + T, *s_kpop = s_lc + T, *s_cnt = s_kpop + T;
+  float *s_tail = reinterpret_cast<float *>(s_cnt + T);
+  int *s_passed = reinterpret_cast<int *>(s_tail + T), *s_ovf = s_passed + T, *s_ovfsp = s_ovf + T;
+  int2 *s_light = reinterpret_cast<int2 *>(s_ovfsp + T);  // [2][epb * I]
+  float *s_rew = reinterpret_cast<float *>(s_light + 2 * (size_t)epb * I);
+  int *s_pdst = reinterpret_cast<int *>(s_rew + (size_t)epb * I);
+  int *s_act = s_pdst + (size_t)epb * I;
+  int *s_ovftick = s_act + (size_t)epb * I;  // [epb] tick + 1 of the env's last overflow in this call
+  int *s_fartick = s_ovftick + epb;          // [epb] tick + 1 of the last tick that needs the serial loop
+  int *s_maxpop = s_fartick + epb;           // [2] most cars any road popped, by tick parity
+
+  const int t = threadIdx.x;
+  const int env_l = t / R, e = t - env_l * R;
+  const int env = blockIdx.x * epb + env_l;
+  const bool valid = env_l < epb && env < d.E;
+  const int id = valid ? env * R + e : 0;
+  const int tick0 = *d.tickA;  // advanced by k_tick_add after this kernel, never inside it
+  const bool train = valid && e < d.r;
+  const int dir = train ? e / I : 0;
+  const int isec = train ? e - dir * I : 0;
+  const int li = env_l * I + isec;  // index of the dest intersection in the per-block arrays
+  const int phase_e = (dir < 2) ? 1 : 0;  // roadgraph.py:36
+  const int ej = valid ? d.entry_idx[e] : -1;
+  const int pe = valid ? d.pred[e] : -1;
+  const int nx = train ? d.nexts[e] : -1;
+  const int tn = t - e + nx, tp = t - e + pe;  // lanes of the next / previous road
+  const bool des = train && dir == 0;          // this lane also keeps intersection `isec`
+  auto RG = [&](int slot, int lane) -> float2 & { return ring[(size_t)(slot - 1) * T + lane]; };
+  auto RW = [&](int slot, int lane) -> float & { return ringw[(size_t)(slot - 1) * T + lane]; };
+
+  // ---- load: ring indices, cars (either global layout -> ring slots), light words ---------------
+  int ld = 1, lc = 1;
+  if (valid) {
+    ld = d.leading[id];
+    lc = d.lastcar[id];
+    const int n = ring_count(ld, lc, C);
+    int slot = ld;
+    if (d.layout == 1) {
+      const size_t col = tcol(d, env, e);
+      for (int k = 0; k < n; ++k) {
+        slot = wrap1(slot + 1, C);
+        RG(slot, t) = d.xv[col + (size_t)k * 64];
+        if (W) RW(slot, t) = d.w[col + (size_t)k * 64];
+      }
+    } else {
+      for (int k = 0; k < n; ++k) {
+        slot = wrap1(slot + 1, C);
+        RG(slot, t) = d.xv[(size_t)id * C + slot];
+        if (W) RW(slot, t) = d.w[(size_t)id * C + slot];
+      }
+    }
+    s_ld[t] = ld;
+    s_lc[t] = lc;
+    s_cnt[t] = n;
+    s_tail[t] = d.tailx[id];
+    s_kpop[t] = 0;
+    s_ovf[t] = 0;
+    if (train) s_passed[t] = d.obs[(size_t)env * d.obs_len + e];
+    if (des) {
+      const int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+      s_light[(size_t)epb * I + li] = make_int2(ob[isec], ob[I + isec]);  // parity 1: read by tick 0
+      s_rew[li] = d.rewards[(size_t)env * I + isec];
+      s_pdst[li] = 0;
+      s_act[li] = a.greedy_spacing > 0 ? a.greedy_act[(size_t)env * I + isec] : 0;
+    }
+    if (e == 0) {
+      s_ovftick[env_l] = 0;
+      s_fartick[env_l] = 0;
+    }
+  }
+  if (t == 0) s_maxpop[0] = s_maxpop[1] = 0;
+  __syncthreads();
+
+  int wait_acc = 0, det = 0;
+  bool det_set = false;
+  float xL = INFINITY;
+  bool xL_set = false;
+  unsigned long long my_updates = 0;
+
+  for (int tt = 0; tt < a.n_ticks; ++tt) {
+    const int tick = tick0 + tt, par = tt & 1;
+    // env stopped for the rest of the agent step (`if done: break`): it overflowed earlier in this call
+    const bool frozen = d.agent_mode && valid && s_ovftick[env_l] > tick0;
+    const bool run = valid && !frozen;
+    int kpop = 0, n_tot = 0, ovf_sp = 0;
+    float tail_x = 0.0f;
+    bool far = false;
+    if (des && frozen) {
+      s_light[(size_t)par * epb * I + li] = s_light[(size_t)(par ^ 1) * epb * I + li];
+      // (the per-tick path's k_greedy keeps deciding for a stopped env, from its standing counts)
+      if (a.greedy_spacing > 0 && tick % a.greedy_spacing == 0) {
+        const int b = t - e + isec;
+        s_act[li] = (s_cnt[b] + s_cnt[b + I] - s_cnt[b + 2 * I] - s_cnt[b + 3 * I] < 0) ? 1 : 0;
+      }
+    }
+    if (run) {
+      ld = s_ld[t];
+      lc = s_lc[t];
+      const int n_old = ring_count(ld, lc, C);
+      n_tot = n_old;
+      // ---- lights (TrafficEnv._step :225-232, update_lights :81-94) ------------------------------
+      xL = INFINITY;
+      xL_set = true;
+      if (train) {
+        const int2 pl = s_light[(size_t)(par ^ 1) * epb * I + li];
+        int ph_new, el_new;
+        if (a.greedy_spacing > 0) {
+          // greedy: every `spacing` ticks phase 1 iff the two N-S approaches hold more cars than the
+          // two E-W ones (cars_on_roads().dot([1,1,-1,-1]) < 0); held in between
+          int act = s_act[li];
+          if (tick % a.greedy_spacing == 0) {
+            const int b = t - e + isec;
+            act = (s_cnt[b] + s_cnt[b + I] - s_cnt[b + 2 * I] - s_cnt[b + 3 * I] < 0) ? 1 : 0;
+          }
+          int change;
+          if (d.learn_switch) { change = act != 0; ph_new = ((pl.x != 0) != (act != 0)) ? 1 : 0; }
+          else { change = (pl.x != 0) != (act != 0); ph_new = act; }
+          el_new = change ? 0 : pl.y + 1;
+          if (des && tick % a.greedy_spacing == 0) s_act[li] = act;  // (read by the others in later ticks only)
+        } else {
+          light_next(d, env, isec, tick, tt, pl.x, pl.y, ph_new, el_new);
+        }
+        if (des) s_light[(size_t)par * epb * I + li] = make_int2(ph_new, el_new);
+        if (phase_e == ph_new || el_new < d.yellow) xL = d.length;
+        else if (s_cnt[tn] > 0) xL = s_tail[tn] + d.length;
+      }
+      // ---- spawns (add_new_cars :274-283 -> add_car :97-114): straight into the ring -------------
+      tail_x = s_tail[t];
+      if (ej >= 0) {
+        const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+        const int c = spawn_count(d, env, e, ej, tick_sp, tt);
+        for (int q = 0; q < c; ++q) {
+          const int pos = wrap1(lc + 1, C);
+          const float start = (lc != ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+          if (pos != ld) {
+            const float xs = (start < 0.0f) ? start : 0.0f;  // min(car.x = 0, start)
+            RG(pos, t) = make_float2(xs, d.car_v);
+            if (W) RW(pos, t) = (float)tick;
+            ++n_tot;
+            lc = pos;
+            tail_x = xs;
+          } else {
+            ++ovf_sp;
+          }
+        }
+      }
+    }
+    // ---- move_cars (:187-212): the lane walks its road from the head, leader chain in registers ---
+    {
+      int kmax = run ? n_tot : 0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(kmax, off, 64);
+        kmax = o > kmax ? o : kmax;
+      }
+      kmax = __builtin_amdgcn_readfirstlane(kmax);
+      float xprev = xL, vprev = 0.0f, llv = 0.0f;
+      int n_wait = 0, n_det = 0;
+      bool open = true;
+      // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
+      const int kq = (ld > lc) ? C - 1 - ld : 0x7fffffff;
+      int slot = wrap1(ld + 1, C);
+      float2 nxt = (n_tot > 0) ? RG(slot, t) : make_float2(0.0f, 0.0f);
+      for (int k = 0; k < kmax; ++k) {
+        const bool act = k < n_tot;
+        const float2 cur = nxt;
+        const int cs = slot;
+        slot = wrap1(slot + 1, C);
+        if (k + 1 < n_tot) nxt = RG(slot, t);
+        const bool off_domain = __builtin_amdgcn_ballot_w64(act && !idm_fast_domain(cur.y)) != 0ull;
+        if (act) {
+          float xn, vn;
+          if (d.fastdiv && !off_domain) idm_step_fast(d, cur.x, cur.y, xprev, vprev, llv, xn, vn);
+          else idm_step(d, cur.x, cur.y, xprev, vprev, llv, xn, vn);
+          xprev = cur.x;  // OLD state leads the next car (Jacobi)
+          vprev = cur.y;
+          llv = d.car_l;
+          RG(cs, t) = make_float2(xn, vn);
+          const bool pop = open && (xn > d.length);  // the while loop of :123
+          open = pop;
+          kpop += pop ? 1 : 0;
+          far = far || (pop && ((xn - d.length) > d.length));
+          const float wq = (k >= kq) ? xn : vn;
+          n_wait += (wq < d.thresh) ? 1 : 0;
+          n_det += (xn > d.near_end) ? 1 : 0;
+          tail_x = xn;
+        }
+      }
+      if (run) {
+        if (train) {
+          if (n_tot > 0) {
+            wait_acc += n_wait;
+            det = n_det;
+            det_set = true;
+          }
+          s_passed[t] = (d.agent_mode && tt > 0) ? s_passed[t] + kpop : kpop;
+          if (kpop > 0) s_pdst[li] = 1;
+        }
+        s_kpop[t] = kpop;
+        s_lc[t] = lc;
+        s_ovfsp[t] = ovf_sp;
+        if (far) s_fartick[env_l] = tick + 1;
+        if (kpop > 0) atomicMax(&s_maxpop[par], kpop);
+        my_updates += (unsigned long long)n_tot;
+      }
+    }
+    __syncthreads();  // B1: every ring holds its post-move cars, pops are published
+
+    // ---- advance_finished_cars (:117-135) -------------------------------------------------------
+    if (t == 0) s_maxpop[par ^ 1] = 0;
+    const bool serial_env = valid && s_fartick[env_l] == tick + 1;
+    const int rounds = (s_maxpop[par] + RES_KH - 1) / RES_KH;
+    const bool pull = run && !serial_env;
+    const int ld_post = ring_adv(ld, kpop, C);
+    const int k_p = (pull && pe >= 0) ? s_kpop[tp] : 0;
+    const int ld_seen = (pe < e) ? ld : ld_post;  // p's pushes see leading[e] before e's own pops iff p < e
+    int ovf = 0;
+    if (serial_env && e == 0 && run) {
+      // literal single-lane loop for this env (a handed-off car is itself beyond the next road's end)
+      const int b = t;  // lane of road 0
+      float *rew = s_rew + (size_t)env_l * I;
+      int overflowed = 0;
+      if (!(d.accum_rewards && tt > 0))
+        for (int i = 0; i < I; ++i) rew[i] = 0.0f;
+      for (int q = 0; q < R; ++q) {  // spawn overflows happened before move_cars
+        const int sp = s_ovfsp[b + q];
+        if (sp > 0) {
+          overflowed = 1;
+          if (q < d.r)
+            for (int j = 0; j < sp; ++j) rew[q % I] -= d.ovf_pen;
+        }
+      }
+      for (int q = 0; q < d.r; ++q) s_passed[b + q] -= s_kpop[b + q];  // the parallel form's counts: recounted below
+      for (int q = 0; q < R; ++q) {
+        const int tq = b + q;
+        int l = s_ld[tq];
+        while (l != s_lc[tq] && RG(wrap1(l + 1, C), tq).x > d.length) {
+          const int newlead = wrap1(l + 1, C);
+          const int nr = d.nexts[q];
+          if (nr >= 0) {
+            s_passed[tq] += 1;
+            s_pdst[env_l * I + q % I] = 1;
+            const float xc = RG(newlead, tq).x - d.length;
+            const int tr = b + nr;
+            const int lcn = s_lc[tr], ldn = s_ld[tr];
+            const int pos = wrap1(lcn + 1, C);
+            const float start = (lcn != ldn) ? (RG(lcn, tr).x - d.car_l) - d.car_s0 : INFINITY;
+            if (pos != ldn) {
+              RG(pos, tr) = make_float2((start < xc) ? start : xc, RG(newlead, tq).y);
+              if (W) RW(pos, tr) = RW(newlead, tq);
+              s_lc[tr] = pos;
+            } else {
+              if (nr < d.r) rew[nr % I] -= d.ovf_pen;
+              overflowed = 1;
+            }
+          }
+          l = newlead;
+          s_ld[tq] = l;
+        }
+      }
+      for (int q = 0; q < R; ++q) {
+        const int tq = b + q;
+        const int n = ring_count(s_ld[tq], s_lc[tq], C);
+        s_cnt[tq] = n;
+        s_tail[tq] = (n > 0) ? RG(s_lc[tq], tq).x : 0.0f;
+        s_ovf[tq] = 0;
+      }
+      if (overflowed) {
+        s_ovftick[env_l] = tick + 1;
+        d.done_tick[env] = tick + 1;
+      }
+    }
+    for (int rd = 0; rd < rounds; ++rd) {
+      float2 car[RES_KH];
+      float carw[RES_KH];
+      int cnt = k_p - rd * RES_KH;
+      cnt = cnt < 0 ? 0 : (cnt > RES_KH ? RES_KH : cnt);
+      if (cnt > 0) {
+        const int head_p = wrap1(s_ld[tp] + 1, C);
+#pragma unroll
+        for (int j = 0; j < RES_KH; ++j)
+          if (j < cnt) {
+            const int sp = ring_adv(head_p, rd * RES_KH + j, C);
+            car[j] = RG(sp, tp);
+            if (W) carw[j] = RW(sp, tp);
+          }
+      }
+      __syncthreads();  // B2: the popped cars of this round are in registers everywhere
+#pragma unroll
+      for (int j = 0; j < RES_KH; ++j)
+        if (j < cnt) {
+          const float xc = car[j].x - d.length;  // state[e,xi,newlead] -= length (:130)
+          const int pos = wrap1(lc + 1, C);
+          const float start = (lc != ld_seen) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+          if (pos != ld_seen) {
+            const float xv = (start < xc) ? start : xc;
+            RG(pos, t) = make_float2(xv, car[j].y);
+            if (W) RW(pos, t) = carw[j];
+            lc = pos;
+            tail_x = xv;
+          } else {
+            ++ovf;
+          }
+        }
+    }
+    if (pull) {
+      const int n = ring_count(ld_post, lc, C);
+      s_cnt[t] = n;
+      s_tail[t] = tail_x;
+      s_ovf[t] = ovf + ovf_sp;
+      if (ovf + ovf_sp > 0) s_ovftick[env_l] = tick + 1;
+    }
+    __syncthreads();  // B3: every road of the pull form has read its predecessor's leading
+    if (pull) {
+      s_ld[t] = ld_post;
+      s_lc[t] = lc;
+    }
+    // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
+    if (des && run && !serial_env) {
+      const int b = t;  // lane of road `isec` (dir 0)
+      const int sum = s_ovf[b] + s_ovf[b + I] + s_ovf[b + 2 * I] + s_ovf[b + 3 * I];
+      float rw = (d.accum_rewards && tt > 0) ? s_rew[li] : 0.0f;
+      for (int j = 0; j < sum; ++j) rw -= d.ovf_pen;
+      s_rew[li] = rw;
+    }
+    if (valid && e == 0 && run && !serial_env && s_ovftick[env_l] == tick + 1) d.done_tick[env] = tick + 1;
+    // (no barrier here: what the next tick reads before its first barrier - s_cnt / s_tail of the next
+    // road, the light words of the other parity, the overflow stamps - was written before B3)
+  }
+  __syncthreads();
+
+  // ---- store ------------------------------------------------------------------------------------
+  if (valid) {
+    ld = s_ld[t];
+    lc = s_lc[t];
+    const int n = s_cnt[t];
+    int slot = ld;
+    if (d.layout == 1) {
+      const size_t col = tcol(d, env, e);
+      for (int k = 0; k < n; ++k) {
+        slot = wrap1(slot + 1, C);
+        d.xv[col + (size_t)k * 64] = RG(slot, t);
+        if (W) d.w[col + (size_t)k * 64] = RW(slot, t);
+      }
+      if (xL_set) d.leadx[id] = xL;
+    } else {
+      for (int k = 0; k < n; ++k) {
+        slot = wrap1(slot + 1, C);
+        d.xv[(size_t)id * C + slot] = RG(slot, t);
+        if (W) d.w[(size_t)id * C + slot] = RW(slot, t);
+      }
+      if (xL_set) d.xv[(size_t)id * C + ld].x = xL;  // the fake leader's x sits in its slot (:133)
+    }
+    d.leading[id] = ld;
+    d.lastcar[id] = lc;
+    d.tailx[id] = s_tail[t];
+    int *ob = d.obs + (size_t)env * d.obs_len;
+    if (train) {
+      ob[e] = s_passed[t];
+      if (det_set) ob[d.r + e] = det;
+      if (wait_acc) d.waiting[(size_t)env * d.r + e] += wait_acc;
+    }
+    if (des) {
+      const int2 pl = s_light[(size_t)((a.n_ticks - 1) & 1) * epb * I + li];
+      ob[2 * d.r + isec] = pl.x;
+      ob[2 * d.r + I + isec] = pl.y;
+      d.rewards[(size_t)env * I + isec] = s_rew[li];
+      if (s_pdst[li]) d.passed_dst[(size_t)env * I + isec] = 1;
+      if (a.greedy_spacing > 0) a.greedy_act[(size_t)env * I + isec] = s_act[li];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if ((t & 63) == 0 && my_updates) veh_add(d.veh, my_updates);
+}
+
+// the device clock after a resident launch (a separate launch: every workgroup of k_res reads tickA)
+__global__ void k_tick_add(const Dev d, int n_ticks) {
+  const int t = *d.tickA + n_ticks;
+  *d.tickA = t;
+  *d.tickB = t - 1;
+}
+
+}  // namespace tfx

@@ -414,7 +414,7 @@ class TfxEngine(object):
         return dict(enabled=bool(en.value), mismatches=int(bad.value))
 
     def fused_ticks(self):
-        """(ticks tfx_step has run fused in k_line so far, whether this handle can fuse at all)."""
+        """(ticks run so far by the LDS-resident multi-tick kernel k_res, whether this handle's envs fit it)."""
         n, cap = C.c_int64(), C.c_int32()
         nat.check(self.lib.tfx_fused_ticks(self.h, C.byref(n), C.byref(cap)))
         return int(n.value), bool(cap.value)

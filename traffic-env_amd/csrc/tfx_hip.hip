@@ -329,7 +329,7 @@ int launch_inputs(tfx_handle h, hipStream_t st) {
 }
 
 // k_res: how many envs a workgroup takes (0 = not applicable).  Limits: one lane per road and at most
-// 1024 lanes; the rings of the workgroup's envs in the LDS a workgroup may have (asked from the
+// RES_MAX_THREADS lanes; the rings of the workgroup's envs in the LDS a workgroup may have (asked from the
 // runtime with hipFuncSetAttribute: 160 KB per CU on gfx950).
 template <bool W>
 int res_configure(tfx_handle h) {
@@ -337,7 +337,7 @@ int res_configure(tfx_handle h) {
   h->res_epb = 0;
   if (const char *rv = getenv("TFX_RESIDENT")) if (atoi(rv) == 0) return TFX_OK;
   if (const char *mt = getenv("TFX_RES_MIN_TICKS")) h->res_min_ticks = atoi(mt);
-  if (d.R > 1024) return TFX_OK;
+  if (d.R > RES_MAX_THREADS) return TFX_OK;
   const size_t lds_cap = 160 * 1024;
   int want = (d.E + h->n_cu - 1) / h->n_cu;  // spread the envs over the chip first
   if (const char *ev = getenv("TFX_RES_EPB")) want = atoi(ev);
@@ -348,7 +348,7 @@ int res_configure(tfx_handle h) {
   for (int k = 1; k <= want; ++k) {
     const int th = (k * d.R + 63) / 64 * 64;
     const size_t b = res_lds_bytes(th, d.C, k, d.I, W);
-    if (th > 1024 || b > lds_cap) break;
+    if (th > RES_MAX_THREADS || b > lds_cap) break;
     epb = k; threads = th; lds = b;
   }
   if (epb == 0) return TFX_OK;

@@ -25,6 +25,7 @@
 #pragma once
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
+#include "tfx_move_t2.hpp"
 
 namespace tfx {
 
@@ -36,6 +37,7 @@ struct ResArgs {
 };
 
 constexpr int RES_KH = 2;  // popped cars copied per handoff round
+constexpr int RES_MAX_THREADS = 512;  // lanes (= roads) per workgroup: 8 wavefronts, up to 256 VGPRs each
 
 // bytes of dynamic LDS for T lanes
 __host__ __device__ inline size_t res_lds_bytes(int T, int C, int epb, int I, bool W) {
@@ -49,7 +51,7 @@ __host__ __device__ inline size_t res_lds_bytes(int T, int C, int epb, int I, bo
 }
 
 template <bool W>
-__global__ __launch_bounds__(1024) void k_res(const Dev d, const ResArgs a) {
+__global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResArgs a) {
   extern __shared__ __align__(16) unsigned char res_smem[];
   const int T = blockDim.x, C = d.C, NS = C - 1, R = d.R, I = d.I;
   const int epb = a.epb;
@@ -217,31 +219,88 @@ __global__ __launch_bounds__(1024) void k_res(const Dev d, const ResArgs a) {
       bool open = true;
       // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
       const int kq = (ld > lc) ? C - 1 - ld : 0x7fffffff;
+      // Groups of G cars computed together, as in k_move_t2: the kernel runs one or two wavefronts
+      // per SIMD, so what it waits for is the dependent-instruction chain of a car's IDM step -
+      // cars k and k+1 are independent (both read OLD values), their arithmetic issues packed
+      // (v_pk_*_f32 on the pair) and the pairs of a group interleave; one domain test per group
+      // decides between idm_pair and the literal idm_step.  Lanes past their road's end compute on
+      // zeros; only the ring writes and the counters are predicated.
+      constexpr int G = 4;
+      const bool fast_ok = d.fastdiv && d.fastmax;
       int slot = wrap1(ld + 1, C);
-      float2 nxt = (n_tot > 0) ? RG(slot, t) : make_float2(0.0f, 0.0f);
-      for (int k = 0; k < kmax; ++k) {
-        const bool act = k < n_tot;
-        const float2 cur = nxt;
-        const int cs = slot;
+      int psl[G];
+      float2 pf[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        psl[u] = slot;
+        pf[u] = (u < n_tot) ? RG(slot, t) : make_float2(0.0f, 0.0f);
         slot = wrap1(slot + 1, C);
-        if (k + 1 < n_tot) nxt = RG(slot, t);
-        const bool off_domain = __builtin_amdgcn_ballot_w64(act && !idm_fast_domain(cur.y)) != 0ull;
-        if (act) {
-          float xn, vn;
-          if (d.fastdiv && !off_domain) idm_step_fast(d, cur.x, cur.y, xprev, vprev, llv, xn, vn);
-          else idm_step(d, cur.x, cur.y, xprev, vprev, llv, xn, vn);
-          xprev = cur.x;  // OLD state leads the next car (Jacobi)
-          vprev = cur.y;
-          llv = d.car_l;
-          RG(cs, t) = make_float2(xn, vn);
-          const bool pop = open && (xn > d.length);  // the while loop of :123
+      }
+      for (int k0 = 0; k0 < kmax; k0 += G) {
+        float2 cur[G];
+        int csl[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          cur[u] = pf[u];
+          csl[u] = psl[u];
+        }
+        if (k0 + G < kmax) {
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            psl[u] = slot;
+            pf[u] = (k0 + G + u < n_tot) ? RG(slot, t) : make_float2(0.0f, 0.0f);
+            slot = wrap1(slot + 1, C);
+          }
+        }
+        float xl[G], vl[G], ll[G], bden[G];
+        xl[0] = xprev;
+        vl[0] = vprev;
+        ll[0] = llv;
+#pragma unroll
+        for (int u = 1; u < G; ++u) {
+          xl[u] = cur[u - 1].x;
+          vl[u] = cur[u - 1].y;
+          ll[u] = d.car_l;
+        }
+        bool ok = t2_v_ok(vprev);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          bden[u] = ((xl[u] - cur[u].x) - ll[u]) + d.eps;
+          ok = ok && t2_v_ok(cur[u].y) && (__builtin_fabsf(bden[u]) >= TFX_T2_B_LO);
+        }
+        float xn[G], vn[G];
+        if (fast_ok && __builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+          for (int u = 0; u < G; u += 2) {
+            v2f x2, v2, vl2, b2, xo, vo;
+            x2.x = cur[u].x; x2.y = cur[u + 1].x;
+            v2.x = cur[u].y; v2.y = cur[u + 1].y;
+            vl2.x = vl[u]; vl2.y = vl[u + 1];
+            b2.x = bden[u]; b2.y = bden[u + 1];
+            idm_pair(d, x2, v2, vl2, b2, xo, vo);
+            xn[u] = xo.x; xn[u + 1] = xo.y;
+            vn[u] = vo.x; vn[u + 1] = vo.y;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < G; ++u) idm_step(d, cur[u].x, cur[u].y, xl[u], vl[u], ll[u], xn[u], vn[u]);
+        }
+        xprev = cur[G - 1].x;  // OLD state leads the next car (Jacobi)
+        vprev = cur[G - 1].y;
+        llv = d.car_l;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int k = k0 + u;
+          const bool act = k < n_tot;
+          if (act) RG(csl[u], t) = make_float2(xn[u], vn[u]);
+          const bool pop = open && act && (xn[u] > d.length);  // the while loop of :123
           open = pop;
           kpop += pop ? 1 : 0;
-          far = far || (pop && ((xn - d.length) > d.length));
-          const float wq = (k >= kq) ? xn : vn;
-          n_wait += (wq < d.thresh) ? 1 : 0;
-          n_det += (xn > d.near_end) ? 1 : 0;
-          tail_x = xn;
+          far = far || (pop && ((xn[u] - d.length) > d.length));
+          const float wq = (k >= kq) ? xn[u] : vn[u];
+          n_wait += (act && wq < d.thresh) ? 1 : 0;
+          n_det += (act && xn[u] > d.near_end) ? 1 : 0;
+          tail_x = act ? xn[u] : tail_x;
         }
       }
       if (run) {

@@ -88,7 +88,7 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
   if (!(d.accum_rewards && tidx > 0))
     for (int i = 0; i < d.I; ++i) rew[i] = 0.0f;
   for (int e = 0; e < d.R; ++e) {
-    const int sp = d.rec[env * d.R + e].y;  // spawn overflows happened before move_cars
+    const int sp = rec_ovf_sp(d.rec[env * d.R + e].y);  // spawn overflows happened before move_cars
     if (sp > 0) {
       overflowed = 1;
       if (e < d.r)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
 #pragma unroll
         for (int dir = 0; dir < 4; ++dir) {
           const int e = dir * d.I + s;
-          ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + d.rec[env * d.R + e].y;
+          ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
         }
         // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
         float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
           const int rxx = d.rec[idx].x;
           int ps = rec_head(rxx);
           for (int j = 0; j < rec_kpop(rxx); ++j) {
-            // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed)
-            const float cw = !d.w ? 0.0f : (TL ? d.outw[tpos(d, idx, j)] : d.w[(size_t)idx * d.C + ps]);
+            // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed; <= 2 pops here)
+            const float cw = !d.w ? 0.0f : (TL ? d.outw[ocol_of(d, env, x) + (size_t)j * 64] : d.w[(size_t)idx * d.C + ps]);
             if (d.trip_times && t < d.trip_cap)
               d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
             ++t;

@@ -48,12 +48,14 @@ struct Dev {
   // slot % 64, G tiles per env); slot_road is the inverse (-1 = padding lane)
   const int *road_slot, *slot_road;
   int G;
-  int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T and in the outbox: >= C - 2
-  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows, bits of post-move tail x, live cars}
-  // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; cars that left a road this
-  // tick wait in its outbox column; the fake leader's x has no slot of its own and lives in leadx
+  int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T: >= C - 2
+  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows | uncompacted << 30, bits of post-move tail x, live cars}
+  // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; the first TFX_KP = 2 cars that
+  // left a road this tick wait in its outbox column outb[tile][j][64], j < KP - a road that pops more
+  // stays uncompacted for the tick and its env takes the serial advance; the fake leader's x has no
+  // slot of its own and lives in leadx
   float2 *outb;
-  float *outw;  // outbox of the spawn-tick plane (transposed layout with planes = 3); w itself is T-shaped
+  float *outw;  // outbox of the spawn-tick plane (planes = 3)
   float *leadx;
   int layout;
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
@@ -255,6 +257,10 @@ __device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int
 // rec.x of a road: number of cars popped this tick (they sit in ring slots head, head+1, ...)
 __device__ __forceinline__ int rec_pack(int kpop, int ld, int C) { return kpop | (wrap1(ld + 1, C) << 16); }
 __device__ __forceinline__ int rec_kpop(int rx) { return rx & 0xffff; }
+// rec.y: spawn overflows of the tick | "the road was left uncompacted" (transposed layout, > TFX_KP pops)
+__device__ __forceinline__ int rec_y(int ovf_sp, bool unc) { return ovf_sp | (unc ? (1 << 30) : 0); }
+__device__ __forceinline__ int rec_ovf_sp(int ry) { return ry & 0x3fffffff; }
+__device__ __forceinline__ bool rec_unc(int ry) { return (ry >> 30) & 1; }
 __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 
 // The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car

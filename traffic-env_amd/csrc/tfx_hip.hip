@@ -252,7 +252,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     if (cap <= 128) return gs(k_move_ts<32>);
     return gs(k_move_ts<64>);
   }
-  if (h->d.w) return go(k_move_t<4, 3, false, true>);  // validate mode: the spawn-tick plane travels along
+  if (h->d.w) return go(k_move_t<4, 3, true>);  // validate mode: the spawn-tick plane travels along
   // k_move_t2 (tfx_move_t2.hpp): packed-pair arithmetic, one domain test per group of 2 / 4 / 8 rows -
   // a third fewer vector instructions, bit-identical, and measured 2-3 % SLOWER than k_move_t at cfg2
   // (same box: 0.670 / 0.664 / 0.678 ms against 0.651): the launch is not VALU-limited.
@@ -266,7 +266,6 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   if (pvar == 54) return go(k_move_t<4>);           // default caching policy (0.82 ms at cfg2)
   if (pvar == 58) return go(k_move_t<8>);
   if (pvar == 68) return go(k_move_t<8, 3>);
-  if (pvar == 88) return go(k_move_t<8, 3, true>);  // loads and stores in 8-row groups
   // every row is read once and written once per tick: non-temporal loads AND stores (0.82 -> 0.70 ms
   // at cfg2, and the following k_advance no longer waits for dirty lines: 0.057 -> 0.032 ms)
   return go(k_move_t<4, 3>);
@@ -574,8 +573,10 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
   d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
-  const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_tpairs * sizeof(float2) : 0), 256);
-  const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_tpairs * sizeof(float) : 0), 256);
+  // outbox: TFX_KP rows per tile (the cars a road hands over in a tick; round 1 kept a T-sized one)
+  const size_t n_opairs = (size_t)d.E * d.G * KP * 64;
+  const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_opairs * sizeof(float2) : 0), 256);
+  const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_opairs * sizeof(float) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_misc = off;  off = align_up(off + 64, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);

@@ -10,8 +10,12 @@
 //     the fake leader (update_lights :81-94) seeds the chain;
 //   * waiting / detected counts and the pop prefix (advance_finished_cars :123: cars leave from the
 //     head while x > length) are per-lane running values - no ballots, no scans;
-//   * survivors are written back compacted (car k goes to position k - pops so far), cars that left
-//     go to the road's outbox column; both stores are row-shaped and coalesce like the loads;
+//   * survivors are written back compacted (car k goes to position k - pops so far) with row-shaped
+//     stores that coalesce like the loads; the first TFX_KP = 2 cars that left go to the road's
+//     outbox column (two rows per tile).  A road that pops MORE than two cars in a tick (only
+//     pathological states do) is left uncompacted for this tick - from the third pop on every car,
+//     popped or not, stays in its own row - and its env takes the serial advance, which reads the
+//     popped cars from the outbox / the head rows and compacts afterwards (tfx_advance_t.hpp);
 //   * rows beyond a road's car count are neither read nor written, so only live cars move.
 // Rows k+1..k+P are in flight while row k is computed (register prefetch).  Per 64 cars this is
 // ~65 vector instructions against ~110 per (up to 64-car) road for the lane-per-car kernels, and
@@ -30,17 +34,18 @@ __device__ __forceinline__ size_t tcol(const Dev &d, int env, int e) {
   const int s = d.road_slot[e];
   return ((size_t)env * d.G + (size_t)(s >> 6)) * (size_t)d.trows * 64 + (size_t)(s & 63);
 }
+// index of row 0 of road e's outbox column (KP rows per tile)
+__device__ __forceinline__ size_t ocol_of(const Dev &d, int env, int e) {
+  const int s = d.road_slot[e];
+  return ((size_t)env * d.G + (size_t)(s >> 6)) * (size_t)KP * 64 + (size_t)(s & 63);
+}
 __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
   const int env = id / d.R;
   return tcol(d, env, id - env * d.R) + (size_t)k * 64;
 }
 
-// BATCH: the walk proceeds in groups of P rows - the P loads of the next group are issued back to
-// back, the group is computed, its P stores are issued back to back - instead of one load and one
-// store per row (longer same-direction bursts at the memory side; tools/copy_probe.hip measures
-// 5.8 TB/s for 4-row and 6.1 TB/s for 8-row groups on this access shape)
 // W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157)
-template <int P, int NT = 0, bool BATCH = false, bool W = false>
+template <int P, int NT = 0, bool W = false>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -64,9 +69,9 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     const int n_sp = run ? p.n_tot - p.n_old : 0;
 
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;     // T[k] of this road = col[k * 64]
-    float2 *ocol = d.outb + ((size_t)tile * d.trows) * 64 + lane;  // outbox column of this road
+    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;       // outbox column of this road (KP rows)
     float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
-    float *owcol = W ? d.outw + ((size_t)tile * d.trows) * 64 + lane : nullptr;
+    float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
     // longest road of the tile (wave-uniform loop bound)
     int kmax = n_old;
@@ -81,6 +86,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // leader of the next car: starts as the fake one
     int kpop = 0, n_wait = 0, n_det = 0;
     bool open = true, far = false;
+    int shift = 0;                   // survivors move up by this many rows: the pops so far, or 0 once
+                                     //   the road popped more than TFX_KP cars and stays uncompacted
     float tail_x = 0.0f;
     // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
     const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
@@ -105,9 +112,6 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         *ptr = make_float2(a, b);
       }
     };
-    float2 outv[P];  // BATCH: survivors of the current group and their destination rows (-1: none)
-    int outrow[P];
-    int ucur = 0;
     auto step = [&](int k, float x, float v, float wv) {
       float xn, vn;
       const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
@@ -122,16 +126,19 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       const bool pop = open && (xn > d.length) && !(d.dbg & 128);  // the while loop of :123 (128: ablation)
       open = pop;
       if (pop) {
-        ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-        if (W) owcol[(size_t)kpop * 64] = wv;
+        if (kpop < KP) {
+          ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+          if (W) owcol[(size_t)kpop * 64] = wv;
+          ++shift;
+        } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
+          shift = 0;
+          st2(&col[(size_t)k * 64], xn, vn);
+          if (W) wcol[(size_t)k * 64] = wv;
+        }
         far = far || ((xn - d.length) > d.length);
-      } else if (BATCH) {
-        outv[ucur] = make_float2(xn, vn);
-        outrow[ucur] = k - kpop;
-        if (W) wcol[(size_t)(k - kpop) * 64] = wv;
       } else {
-        st2(&col[(size_t)(k - kpop) * 64], xn, vn);
-        if (W) wcol[(size_t)(k - kpop) * 64] = wv;
+        st2(&col[(size_t)(k - shift) * 64], xn, vn);
+        if (W) wcol[(size_t)(k - shift) * 64] = wv;
       }
       kpop += pop ? 1 : 0;
       const float wq = (k >= kq) ? xn : vn;
@@ -148,34 +155,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
       pf[u] = (u < n_old) ? ld2(&col[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
       pfw[u] = (W && u < n_old) ? wcol[(size_t)u * 64] : 0.0f;
     }
-    if (BATCH) {
-      for (int k0 = 0; k0 < kmax; k0 += P) {
-        float2 cur[P];
-        float curw[P];
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          cur[u] = pf[u];
-          curw[u] = pfw[u];
-          outrow[u] = -1;
-        }
-        if (k0 + P < kmax) {
-#pragma unroll
-          for (int u = 0; u < P; ++u) {
-            pf[u] = (k0 + P + u < n_old) ? ld2(&col[(size_t)(k0 + P + u) * 64]) : make_float2(0.0f, 0.0f);
-            pfw[u] = (W && k0 + P + u < n_old) ? wcol[(size_t)(k0 + P + u) * 64] : 0.0f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const int k = k0 + u;
-          ucur = u;
-          if (k < n_old) step(k, cur[u].x, cur[u].y, curw[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < P; ++u)
-          if (outrow[u] >= 0) st2(&col[(size_t)outrow[u] * 64], outv[u].x, outv[u].y);
-      }
-    } else {
+    {
       for (int k0 = 0; k0 < kmax; k0 += P) {
 #pragma unroll
         for (int u = 0; u < P; ++u) {
@@ -192,7 +172,6 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         }
       }
     }
-    ucur = 0;
     // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
     if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
       int smax = n_sp;
@@ -202,11 +181,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         smax = o > smax ? o : smax;
       }
       smax = __builtin_amdgcn_readfirstlane(smax);
-      for (int s = 0; s < smax; ++s) {
-        if (BATCH) outrow[0] = -1;
+      for (int s = 0; s < smax; ++s)
         if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick);  // w = spawn tick
-        if (BATCH && outrow[0] >= 0) st2(&col[(size_t)outrow[0] * 64], outv[0].x, outv[0].y);
-      }
     }
 
     // ---- phase W -------------------------------------------------------------------------------
@@ -221,8 +197,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
-      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, __float_as_int(tail_x), n_tot);
-      if (far) d.env_flag[env] = tick + 1;
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
+      if (far || kpop > KP) d.env_flag[env] = tick + 1;
       d.leadx[id] = p.xL;
       my_updates += (unsigned long long)n_tot;
     }

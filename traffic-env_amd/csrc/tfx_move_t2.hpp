@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_move_t2(const Dev d, const int tidx) {
 
     // wave-uniform tile bases; a row is base + 512 * row + 8 * lane
     char *tb = reinterpret_cast<char *>(d.xv + ((size_t)tile * d.trows) * 64);
-    char *ob = reinterpret_cast<char *>(d.outb + ((size_t)tile * d.trows) * 64);
+    char *ob = reinterpret_cast<char *>(d.outb + ((size_t)tile * KP) * 64);
     auto ldrow = [&](int row) {  // row is wave-uniform
       const f2v t = (NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f2v *>(tb + (size_t)row * 512 + lane8))
                              : *reinterpret_cast<const f2v *>(tb + (size_t)row * 512 + lane8);
@@ -162,10 +162,16 @@ __global__ __launch_bounds__(256) void k_move_t2(const Dev d, const int tidx) {
       const bool pop = open && active && (xn > d.length) && !(d.dbg & 128);  // the while loop of :123
       open = pop;
       if (pop) {
-        *reinterpret_cast<f2v *>(ob + (unsigned)kpop * 512u + lane8) = f2v{xn, vn};
+        if (kpop < KP) {
+          *reinterpret_cast<f2v *>(ob + (unsigned)kpop * 512u + lane8) = f2v{xn, vn};
+        } else {  // third pop: from here on every car stays in its own row (see k_move_t)
+          wr = (unsigned)k * 512u + lane8;
+          strow(wr, xn, vn);
+          wr += 512u;
+        }
         far = far || ((xn - d.length) > d.length);
       } else if (active) {
-        strow(wr, xn, vn);
+        strow(wr, xn, vn);  // row k - pops; row k once the road is uncompacted
         wr += 512u;
       }
       kpop += pop ? 1 : 0;
@@ -267,8 +273,8 @@ __global__ __launch_bounds__(256) void k_move_t2(const Dev d, const int tidx) {
         obs[e] = (d.agent_mode && tidx > 0) ? obs[e] + kpop : kpop;
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
-      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), p.ovf_sp, __float_as_int(tail_x), n_tot);
-      if (far) d.env_flag[env] = tick + 1;
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
+      if (far || kpop > KP) d.env_flag[env] = tick + 1;
       d.leadx[id] = p.xL;
       my_updates += (unsigned long long)n_tot;
     }

@@ -9,7 +9,8 @@
 //      prefix closes (usually one or two rows; any number is handled),
 //   2. loads its cars (and the one in front of its first) into registers and computes them,
 //   3. workgroup barrier - every read of old rows has happened - then writes the survivors compacted
-//      (row k - pops) and the popped cars to the outbox, exactly as k_move_t does,
+//      (row k - pops) and the first TFX_KP popped cars to the outbox, exactly as k_move_t does (a
+//      road with more than TFX_KP pops is written back uncompacted, every car in its own row),
 //   4. the per-road counts meet in LDS and segment 0 writes the road's outputs.
 // Same arithmetic, same stores: results are bit-identical to k_move_t (every transposed-layout test
 // runs through this kernel whenever the launch is small).
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
     const int n_old = run ? p.n_old : 0;
     const int n_tot = run ? p.n_tot : 0;
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
-    float2 *ocol = d.outb + ((size_t)tile * d.trows) * 64 + lane;
+    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
     float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
-    float *owcol = W ? d.outw + ((size_t)tile * d.trows) * 64 + lane : nullptr;
+    float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
     int kmax = n_tot;
 #pragma unroll
@@ -144,30 +145,37 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
         }
       }
     }
-    __syncthreads();  // every segment has read the old rows it needs
+    if (seg == S - 1) s_kpop[lane] = kpop;  // the last segment has seen every car in front of it
+    __syncthreads();  // every segment has read the old rows it needs; the road's pop count is known
 
     {
+      const bool unc = s_kpop[lane] > KP;  // > TFX_KP pops: every car back to its own row (see k_move_t)
       int kp = kpop0;
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
         const int k = k0 + u;
         if (k < k1 && k < n_tot) {
           if ((popmask >> u) & 1ull) {
-            ocol[(size_t)kp * 64] = make_float2(cx[u], cv[u]);
-            if (W) owcol[(size_t)kp * 64] = cw[u];
+            if (kp < KP) {     // the road's outbox column
+              ocol[(size_t)kp * 64] = make_float2(cx[u], cv[u]);
+              if (W) owcol[(size_t)kp * 64] = cw[u];
+            } else {           // (uncompacted road) later pops stay in their own rows
+              col[(size_t)k * 64] = make_float2(cx[u], cv[u]);
+              if (W) wcol[(size_t)k * 64] = cw[u];
+            }
             ++kp;
           } else {
-            col[(size_t)(k - kp) * 64] = make_float2(cx[u], cv[u]);
-            if (W) wcol[(size_t)(k - kp) * 64] = cw[u];
+            const int row = unc ? k : k - kp;
+            col[(size_t)row * 64] = make_float2(cx[u], cv[u]);
+            if (W) wcol[(size_t)row * 64] = cw[u];
           }
         }
       }
     }
     s_wait[seg][lane] = n_wait;
     s_det[seg][lane] = n_det;
-    if (seg == S - 1) s_kpop[lane] = kpop;  // the last segment has seen every car in front of it
     if (has_tail || (seg == 0 && n_tot == 0)) s_tail[lane] = tail_x;
-    if (far) d.env_flag[env] = tick + 1;
+    if (far || kpop > KP) d.env_flag[env] = tick + 1;
     __syncthreads();
 
     if (seg == 0 && run) {
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
         ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop_all : kpop_all;
         if (kpop_all > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
-      d.rec[id] = make_int4(rec_pack(kpop_all, p.ld, C), p.ovf_sp, __float_as_int(s_tail[lane]), n_tot);
+      d.rec[id] = make_int4(rec_pack(kpop_all, p.ld, C), rec_y(p.ovf_sp, kpop_all > KP), __float_as_int(s_tail[lane]), n_tot);
       d.leadx[id] = p.xL;
       my_updates += (unsigned long long)n_tot;
     }

@@ -155,6 +155,13 @@ class TfxEngine(object):
             if self.P == 3:
                 self._ringw = torch.zeros((self.E, self.R, self.C), dtype=torch.float32, device=self.device)
 
+    def drop_staging(self):
+        """Free the ring-shaped staging copy of a transposed handle (it comes back on the next access)."""
+        if self._t is not None:
+            self._ring = None
+            self._ringw = None
+            self._stage_epoch = -1
+
     def _export(self):
         if self._t is not None:
             self._staging()

@@ -87,6 +87,7 @@ def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2, layout
     eng.leading[:] = torch.as_tensor(leading).to(dev)[None]
     eng.lastcar[:] = torch.as_tensor(lastcar).to(dev)[None]
     eng.refresh()
+    eng.drop_staging()                              # the rollout itself never looks at the cars
     eng.set_spawns(period=SPAWN_PERIOD)
     eng.set_actions(cycle_period=LIGHT_PERIOD)
     return eng

@@ -105,14 +105,19 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
 
 
 def load_pmc_traffic(name, kernel):
-    """Per-launch HBM bytes of the move kernel from the committed rocprofv3 PMC summary, if one
-    exists for this workload AND this kernel (profiles/pmc_<cfg>.json, tools/pmc_summary.py)."""
+    """HBM bytes per tick of the kernel that moves the cars, from the committed rocprofv3 PMC summary
+    (profiles/pmc_<cfg>.json, tools/pmc_summary.py) - only if it was taken for this workload, this
+    kernel AND these kernel sources (the summary carries a hash of csrc/); otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pmc_summary import csrc_hash
         with open(path) as f:
             d = json.load(f)
-        return d.get("k_move_hbm_bytes_per_launch") if d.get("kernel") == kernel else None
-    except (OSError, ValueError):
+        if d.get("kernel") != kernel or d.get("csrc_hash") != csrc_hash():
+            return None
+        return d.get("hbm_bytes_per_tick")
+    except (OSError, ValueError, ImportError):
         return None
 
 
@@ -294,7 +299,7 @@ def main():
         move_bytes = 16.0 * live_per_tick + 48.0 * E * eng.R
         tick_bytes = wl.algorithmic_bytes_per_tick(live_per_tick, E * eng.R, E * eng.I)
         achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
-        kernel = "k_move_t" if eng.layout == "transposed" else "k_move_dma"
+        kernel = eng.step_kernel()
         out = {
             "metric": "vehicle_updates_per_sec",
             "value": total_updates / dt_max,

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 7
+#define TFX_ABI_VERSION 8
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -208,12 +208,17 @@ int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, voi
 int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches);
 /* launch geometry of the move kernel, for the roofline report */
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
-/* Ticks of this handle that tfx_step ran fused, several per launch with the cars held in LDS (k_line),
- * since tfx_create, and whether the handle's storage order allows it at all (`capable`: transposed
- * layout with every street line inside one wavefront).  tfx_step fuses on its own whenever it is
- * asked for >= 2 ticks, the spawn rule and the controller do not depend on the cars (no on-device
- * Poisson / greedy), and validate mode is off; results are bit-identical either way. */
+/* Ticks of this handle that ran in the LDS-resident multi-tick kernel (k_res: every tick of a tfx_step
+ * or tfx_agent_step call in ONE launch, the envs' cars held in a compute unit's LDS) since tfx_create,
+ * and whether the handle's envs fit it at all (`capable`: one lane per road, at most 512 lanes and
+ * 160 KB of rings per workgroup - cfg0, cfg1, the reference's 3x3 default do; cfg2 and cfg4 do not).
+ * A capable handle takes k_res on its own unless trip times are recorded (validate mode) or the
+ * arrivals come from the on-device Poisson stream; results are bit-identical either way.
+ * TFX_RESIDENT=0 in the environment (read by tfx_bind_buffers) turns it off. */
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
+/* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
+ * "k_move_dma", ...), for the roofline report; "" before the first step */
+const char *tfx_step_kernel(tfx_handle h);
 
 /* Host-side replay of the reference's seeded arrival generators for many envs (no GPU involved): one
  * stream per env holds a legacy numpy RandomState's MT19937 state (`RandomState.get_state()[1:3]`)

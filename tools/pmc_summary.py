@@ -1,27 +1,47 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories into the small summaries kept under profiles/.
 
-  tools/pmc_summary.py --round r01 --config cfg2 --kt <kernel-trace dir> --pmc <pmc dir> [<pmc dir> ...]
+  tools/pmc_summary.py --round r02 --config cfg2 --kt <kernel-trace dir> --pmc <pmc dir> [<pmc dir> ...]
 
-Writes profiles/<round>_kernel_stats.csv (the --stats table, our kernels only),
+Writes profiles/<round>_kernel_stats_<config>.csv (the --stats table, our kernels only),
 profiles/<round>_pmc_<config>.csv (mean counter value per kernel) and profiles/pmc_<config>.json
-(what bench.py reports as roofline.traffic): HBM bytes per k_move launch from FETCH_SIZE and
-WRITE_SIZE, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 - both are
-in KiB; FETCH_SIZE counts 128-byte requests as 64 bytes for wide (16 B/lane) streaming reads, so
-it is doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
+(what bench.py reports as roofline.traffic): HBM bytes per launch of the kernel that moves the cars
+(--kernel, default: the one of ours with the largest total time) from FETCH_SIZE and WRITE_SIZE,
+corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 - both are in KiB;
+FETCH_SIZE counts 128-byte requests as 64 bytes for wide streaming reads, so it is doubled;
+WRITE_SIZE is exact for streaming stores.  The json carries `csrc_hash` (tools/pmc_summary.py
+--hash prints the current one): bench.py reports the traffic only while the kernels' sources are
+the ones that were profiled.
 """
 import argparse
 import collections
 import csv
 import glob
 import json
+import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_t2", "k_move_t", "k_move")
+
+
+def csrc_hash():
+    """sha256 over the kernel sources and the ABI header (sorted by name), first 16 hex digits."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "traffic-env_amd", "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".hip", ".cpp")))
+    for f in files + [os.path.join(ROOT, "include", "tfx.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
-    for k in ("k_move_dma", "k_move_t", "k_move", "k_advance", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads"):
+    for k in MOVERS + ("k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
+                       "k_poisson", "k_greedy", "k_agent_obs"):
+        if k + "<" in name or k + "(" in name or name.strip().endswith(k):
+            return k
+    for k in MOVERS:
         if k in name:
             return k
     return None
@@ -34,11 +54,22 @@ def main():
     ap.add_argument("--kt", default=None)
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--note", default="")
+    ap.add_argument("--kernel", default=None, help="the kernel whose traffic goes into pmc_<config>.json")
+    ap.add_argument("--ticks-per-launch", type=int, default=1,
+                    help="ticks one launch of that kernel covers (k_res: the n of tfx_step(n))")
+    ap.add_argument("--hash", action="store_true", help="print the current csrc hash and exit")
     a = ap.parse_args()
+    if a.hash:
+        print(csrc_hash())
+        return
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
+    total_ns = collections.Counter()
     if a.kt:
         for f in glob.glob(os.path.join(a.kt, "**", "*_kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if short(r["Name"]) in MOVERS:
+                    total_ns[short(r["Name"])] += int(float(r["TotalDurationNs"]))
             rows = [r for r in csv.DictReader(open(f)) if short(r["Name"])]
             with open(os.path.join(out, "%s_kernel_stats_%s.csv" % (a.round, a.config)), "w") as g:
                 w = csv.writer(g)
@@ -59,14 +90,17 @@ def main():
             w.writerow(["Kernel", "Counter", "Dispatches", "MeanPerDispatch"])
             for (k, c), v in sorted(agg.items()):
                 w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
-        mv = next((k for k in ("k_move_t", "k_move_dma", "k_move") if (k, "FETCH_SIZE") in agg), "k_move")
-        if (mv, "FETCH_SIZE") in agg and (mv, "WRITE_SIZE") in agg:
+        have = [k for k in MOVERS if (k, "FETCH_SIZE") in agg and (k, "WRITE_SIZE") in agg]
+        mv = a.kernel or (max(have, key=lambda k: total_ns.get(k, 0)) if have else None)
+        if mv and (mv, "FETCH_SIZE") in agg and (mv, "WRITE_SIZE") in agg:
             fetch = sum(agg[(mv, "FETCH_SIZE")]) / len(agg[(mv, "FETCH_SIZE")])
             write = sum(agg[(mv, "WRITE_SIZE")]) / len(agg[(mv, "WRITE_SIZE")])
-            js = {"kernel": mv, "config": a.config, "round": a.round,
+            js = {"kernel": mv, "config": a.config, "round": a.round, "csrc_hash": csrc_hash(),
+                  "ticks_per_launch": a.ticks_per_launch,
                   "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
                   "read_bytes": fetch * 1024 * 2, "write_bytes": write * 1024,
                   "k_move_hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+                  "hbm_bytes_per_tick": (fetch * 1024 * 2 + write * 1024) / a.ticks_per_launch,
                   "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of wide streaming reads as 64 B); "
                                 "WRITE_SIZE as reported", "note": a.note}
             json.dump(js, open(os.path.join(out, "pmc_%s.json" % a.config), "w"), indent=1)

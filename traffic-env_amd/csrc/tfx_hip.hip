@@ -75,6 +75,7 @@ struct tfx_handle_s {
   std::vector<int> ev_weight;  // ticks the i-th timed entry covers (1, or the ticks of a fused launch)
   bool prof = false;
   long long fused_ticks = 0;   // ticks run by k_res since tfx_create
+  const char *step_kernel = "";  // the kernel that moved the cars in the last tick (tfx_step_kernel)
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
   size_t move_lds = 0;
@@ -192,6 +193,7 @@ int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds 
 template <int CC, int S, int NBUF, int UNR, bool LDSL, int LIVE = 0, int NP = 1>
 int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
   auto kern = k_move_dma<CC, S, NBUF, UNR, LDSL, LIVE, NP>;
+  h->step_kernel = "k_move_dma";
   if (h->grid_move == 0) {
     h->move_lds = (size_t)4 * NBUF * S * h->d.C * sizeof(float2);
     if (h->move_lds > 64 * 1024)
@@ -206,6 +208,7 @@ int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
 
 template <int WPR>
 int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
+  h->step_kernel = "k_move";
   if (h->grid_move == 0) h->grid_move = move_grid(h, k_move<WPR>, 256 / (64 * WPR));
   if (h->size_only) return TFX_OK;
   hipLaunchKernelGGL(k_move<WPR>, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
@@ -242,33 +245,33 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     };
     const int cap = h->d.C - 2;
     if (h->d.w) {
-      if (cap <= 32) return gs(k_move_ts<8, true>);
-      if (cap <= 64) return gs(k_move_ts<16, true>);
-      if (cap <= 128) return gs(k_move_ts<32, true>);
-      return gs(k_move_ts<64, true>);
+      if (cap <= 32) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<8, true>); }
+      if (cap <= 64) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16, true>); }
+      if (cap <= 128) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<32, true>); }
+      { h->step_kernel = "k_move_ts"; return gs(k_move_ts<64, true>); }
     }
-    if (cap <= 32) return gs(k_move_ts<8>);
-    if (cap <= 64) return gs(k_move_ts<16>);
-    if (cap <= 128) return gs(k_move_ts<32>);
-    return gs(k_move_ts<64>);
+    if (cap <= 32) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<8>); }
+    if (cap <= 64) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16>); }
+    if (cap <= 128) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<32>); }
+    { h->step_kernel = "k_move_ts"; return gs(k_move_ts<64>); }
   }
-  if (h->d.w) return go(k_move_t<4, 3, true>);  // validate mode: the spawn-tick plane travels along
+  if (h->d.w) { h->step_kernel = "k_move_t"; return go(k_move_t<4, 3, true>); }  // validate mode: the spawn-tick plane travels along
   // k_move_t2 (tfx_move_t2.hpp): packed-pair arithmetic, one domain test per group of 2 / 4 / 8 rows -
   // a third fewer vector instructions, bit-identical, and measured 2-3 % SLOWER than k_move_t at cfg2
   // (same box: 0.670 / 0.664 / 0.678 ms against 0.651): the launch is not VALU-limited.
   // Kept as A/B points (102 / 104 / 108; 92 / 94 / 98 = the same, never the four-waves-per-tile kernel).
-  if (pvar == 102 || pvar == 92) return go(k_move_t2<2>);
-  if (pvar == 104 || pvar == 94) return go(k_move_t2<4>);
-  if (pvar == 108 || pvar == 98) return go(k_move_t2<8>);
+  if (pvar == 102 || pvar == 92) { h->step_kernel = "k_move_t2"; return go(k_move_t2<2>); }
+  if (pvar == 104 || pvar == 94) { h->step_kernel = "k_move_t2"; return go(k_move_t2<4>); }
+  if (pvar == 108 || pvar == 98) { h->step_kernel = "k_move_t2"; return go(k_move_t2<8>); }
   // A/B points kept from the tuning runs
-  if (pvar == 51) return go(k_move_t<1, 3>);
-  if (pvar == 52) return go(k_move_t<2, 3>);
-  if (pvar == 54) return go(k_move_t<4>);           // default caching policy (0.82 ms at cfg2)
-  if (pvar == 58) return go(k_move_t<8>);
-  if (pvar == 68) return go(k_move_t<8, 3>);
+  if (pvar == 51) { h->step_kernel = "k_move_t"; return go(k_move_t<1, 3>); }
+  if (pvar == 52) { h->step_kernel = "k_move_t"; return go(k_move_t<2, 3>); }
+  if (pvar == 54) { h->step_kernel = "k_move_t"; return go(k_move_t<4>); }           // default caching policy (0.82 ms at cfg2)
+  if (pvar == 58) { h->step_kernel = "k_move_t"; return go(k_move_t<8>); }
+  if (pvar == 68) { h->step_kernel = "k_move_t"; return go(k_move_t<8, 3>); }
   // every row is read once and written once per tick: non-temporal loads AND stores (0.82 -> 0.70 ms
   // at cfg2, and the following k_advance no longer waits for dirty lines: 0.057 -> 0.032 ms)
-  return go(k_move_t<4, 3>);
+  { h->step_kernel = "k_move_t"; return go(k_move_t<4, 3>); }
 }
 
 // Ring layout.  TFX_MOVE_VARIANT: 0 = automatic | 1 generic k_move<1> | 21/24/26/34 k_move_dma A/B points
@@ -377,11 +380,15 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st) {
   a.greedy_spacing = h->greedy ? h->greedy_spacing : 0;
   a.greedy_act = h->dev_greedy;
   const int grid = (d.E + h->res_epb - 1) / h->res_epb;
+  a.own_clock = grid == 1 ? 1 : 0;
+  h->step_kernel = "k_res";
   if (d.w) hipLaunchKernelGGL(k_res<true>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
   else hipLaunchKernelGGL(k_res<false>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, d, n_ticks);
-  HIPCHK(hipGetLastError());
+  if (!a.own_clock) {  // every workgroup reads the clock at its start: it moves in a launch of its own
+    hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, d, n_ticks);
+    HIPCHK(hipGetLastError());
+  }
   return TFX_OK;
 }
 
@@ -987,6 +994,8 @@ int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable) {
   if (capable) *capable = h->res_epb > 0 ? 1 : 0;
   return TFX_OK;
 }
+
+const char *tfx_step_kernel(tfx_handle h) { return h ? h->step_kernel : ""; }
 
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road) {
   if (int rc = check_handle(h, false)) return rc;

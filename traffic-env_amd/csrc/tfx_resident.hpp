@@ -34,6 +34,7 @@ struct ResArgs {
   int n_ticks;
   int greedy_spacing;  // > 0: the greedy controller decides in the kernel (algorithms/greedy.py:14-16)
   int *greedy_act;     // [E][I] held greedy actions (in/out)
+  int own_clock;       // single-workgroup launch: the kernel advances the device clock itself
 };
 
 constexpr int RES_KH = 2;  // popped cars copied per handoff round
@@ -488,6 +489,10 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   }
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if ((t & 63) == 0 && my_updates) veh_add(d.veh, my_updates);
+  if (a.own_clock && t == 0) {  // (one workgroup: nobody else reads the clock during this launch)
+    *d.tickA = tick0 + a.n_ticks;
+    *d.tickB = tick0 + a.n_ticks - 1;
+  }
 }
 
 // the device clock after a resident launch (a separate launch: every workgroup of k_res reads tickA)

@@ -46,6 +46,32 @@ class HostMirror(object):
         return self.views
 
 
+class PackedMirror(object):
+    """Pinned host copy of ONE contiguous device byte buffer that several tensors are views of: one
+    device-to-host copy and one stream synchronisation bring all of them over.  `views` maps a name
+    to (byte offset, dtype, shape); pull() returns {name: NumPy view} (valid until the next pull)."""
+
+    def __init__(self, device, buf, views):
+        self.device = device
+        self.dev = buf
+        self.host = torch.empty(buf.shape, dtype=torch.uint8).pin_memory()
+        raw = self.host.numpy()
+        self.views = {}
+        for name, (off, dtype, shape) in views.items():
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            self.views[name] = raw[off:off + n].view(dtype).reshape(shape)
+
+    def start(self):
+        """Queue the copy only (a later pull() / synchronisation on the same stream completes it)."""
+        self.host.copy_(self.dev, non_blocking=True)
+        return self.views
+
+    def pull(self):
+        self.host.copy_(self.dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.views
+
+
 class TfxEngine(object):
     def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
                  validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0,
@@ -116,15 +142,30 @@ class TfxEngine(object):
         self._stage_epoch = -1
         self.leading = torch.ones((E, R), dtype=torch.int32, device=dev)
         self.lastcar = torch.ones((E, R), dtype=torch.int32, device=dev)
-        self.obs = torch.zeros((E, self.obs_len), dtype=torch.int32, device=dev)
-        self.rewards = torch.zeros((E, I), dtype=torch.float32, device=dev)
+        # what a caller reads back after a step lives in ONE buffer (obs | rewards | done_tick | n_trips |
+        # done) so that the single-env surface needs one device-to-host copy per step
+        self.trip_cap = int(trip_cap)
+        lay, off = {}, 0
+        for name, dtype, shape in (("obs", np.int32, (E, self.obs_len)), ("rewards", np.float32, (E, I)),
+                                   ("done_tick", np.int32, (E,)), ("n_trips", np.int32, (E,)),
+                                   ("done", np.uint8, (E,))):
+            lay[name] = (off, dtype, shape)
+            off += int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._out = torch.zeros(((off + 15) // 16 * 16,), dtype=torch.uint8, device=dev)
+        self._out_layout = lay
+
+        def view(name, tdtype):
+            o, dtype, shape = lay[name]
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return self._out[o:o + n].view(tdtype).view(*shape)
+        self.obs = view("obs", torch.int32)
+        self.rewards = view("rewards", torch.float32)
+        self.done_tick = view("done_tick", torch.int32)
+        self.done = view("done", torch.uint8)
+        self.n_trips = view("n_trips", torch.int32) if validate else None
         self.waiting = torch.zeros((E, r), dtype=torch.int32, device=dev)
         self.passed_dst = torch.zeros((E, I), dtype=torch.uint8, device=dev)
-        self.done_tick = torch.zeros((E,), dtype=torch.int32, device=dev)
-        self.done = torch.zeros((E,), dtype=torch.uint8, device=dev)
-        self.trip_cap = int(trip_cap)
         self.trip_times = torch.zeros((E, self.trip_cap), dtype=torch.float32, device=dev) if validate else None
-        self.n_trips = torch.zeros((E,), dtype=torch.int32, device=dev) if validate else None
         self._cars = torch.zeros((E, R), dtype=torch.int32, device=dev)
         b = nat.TfxBuffers()
         b.xv = _ptr(self._t if self._t is not None else self._ring)
@@ -335,28 +376,78 @@ class TfxEngine(object):
         slot[3] = True
         return dev, True
 
+    def out_mirror(self):
+        """Pinned mirror of the read-back buffer: pull() -> {'obs', 'rewards', 'done_tick', 'n_trips',
+        'done'} as NumPy views, one copy + one synchronisation."""
+        return PackedMirror(self.device, self._out, self._out_layout)
+
+    def agent_mirror(self):
+        """Pinned mirror of the fused decision's outputs: pull() -> {'aobs', 'areward'}."""
+        if getattr(self, "_aobs", None) is None:
+            raise nat.TfxError("agent_mirror() needs one agent_step() first")
+        na = self.E * (2 * self.r + self.I)
+        lay = {"aobs": (0, np.float32, (self.E, 2 * self.r + self.I)),
+               "areward": (4 * na, np.float32, (self.E, self.I))}
+        return PackedMirror(self.device, self._aout.view(torch.uint8), lay)
+
+    def stage_inputs(self, actions, counts, per_tick=False):
+        """Light actions int [E,I] and arrival counts int [E,n_entry] (per_tick: [n,E,n_entry]) from host
+        arrays through ONE pinned staging buffer and ONE host-to-device copy; binds both inputs."""
+        actions = np.asarray(actions, np.int32).reshape(self.E, self.I)
+        counts = np.asarray(counts, np.int32)
+        na = self.E * self.I
+        key = ("inp", counts.shape)
+        slot = self._stages.get(key)
+        if slot is None:
+            slot = [torch.empty((na + counts.size,), dtype=torch.int32).pin_memory(),
+                    torch.empty((na + counts.size,), dtype=torch.int32, device=self.device), torch.cuda.Event(), False]
+            self._stages[key] = slot
+        pin, dev, ev, used = slot
+        if used:
+            ev.synchronize()
+        h = pin.numpy()
+        h[:na] = actions.ravel()
+        h[na:] = counts.ravel()
+        dev.copy_(pin, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[3] = True
+        a, c = dev[:na], dev[na:]
+        ka = ("held", nat.ACTION_BUFFER, a.data_ptr())
+        if self._action_bound != ka:
+            nat.check(self.lib.tfx_set_actions(self.h, nat.ACTION_BUFFER, _ptr(a), 0, 0))
+            self._action_bound = ka
+        ks = ("per_tick" if per_tick else "held", c.data_ptr())
+        if self._spawn_bound != ks:
+            nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_COUNTS, _ptr(c), 0, 1 if per_tick else 0))
+            self._spawn_bound = ks
+        self._action_buf, self._spawn_buf = a, c
+
     def host_mirror(self, *tensors):
         """Pinned host copies of small device tensors, refreshed together with ONE stream
         synchronisation: mirror.pull() -> list of NumPy views (valid until the next pull)."""
         return HostMirror(self.device, tensors)
 
-    def step(self, n_ticks=1):
+    def step(self, n_ticks=1, update_done=True):
         """n_ticks x TrafficEnv._step (traffic_env.py:224-248) with the inputs set by
-        set_actions / set_spawns.  Updates `done` (overflow in any of these ticks)."""
+        set_actions / set_spawns.  Updates `done` (overflow in any of these ticks) unless the caller
+        derives it from `done_tick` itself (update_done=False saves a launch)."""
         first = self.tick
         self._epoch += 1
         with torch.cuda.device(self.device):
             nat.check(self.lib.tfx_step(self.h, int(n_ticks), self._stream()))
             self.tick += int(n_ticks)
-            nat.check(self.lib.tfx_done(self.h, _ptr(self.done), first, self._stream()))
+            if update_done:
+                nat.check(self.lib.tfx_done(self.h, _ptr(self.done), first, self._stream()))
 
     def agent_step(self, n_ticks=10, remi=True):
         """One agent decision fused on the device (Repeater + Remi of traffic_test.py:27-64) with the
         inputs set by set_actions / set_spawns.  Returns (aobs f32 [E,2r+I], areward f32 [E,I],
         adone u8 [E]) - buffers owned by the engine and overwritten by the next call."""
         if getattr(self, "_aobs", None) is None:
-            self._aobs = torch.zeros((self.E, 2 * self.r + self.I), dtype=torch.float32, device=self.device)
-            self._arew = torch.zeros((self.E, self.I), dtype=torch.float32, device=self.device)
+            na, nr = self.E * (2 * self.r + self.I), self.E * self.I
+            self._aout = torch.zeros((na + nr,), dtype=torch.float32, device=self.device)   # aobs | areward
+            self._aobs = self._aout[:na].view(self.E, 2 * self.r + self.I)
+            self._arew = self._aout[na:].view(self.E, self.I)
             # the decision's done flags ARE the engine's `done` (what reset_done() defaults to)
             self._adone = self.done
         self._epoch += 1
@@ -425,6 +516,10 @@ class TfxEngine(object):
         n, cap = C.c_int64(), C.c_int32()
         nat.check(self.lib.tfx_fused_ticks(self.h, C.byref(n), C.byref(cap)))
         return int(n.value), bool(cap.value)
+
+    def step_kernel(self):
+        """Name of the kernel that moved the cars in the last tick ('k_move_t', 'k_res', ...)."""
+        return self.lib.tfx_step_kernel(self.h).decode()
 
     def launch_info(self):
         v = [C.c_int32() for _ in range(3)]

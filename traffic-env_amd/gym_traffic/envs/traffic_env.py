@@ -193,9 +193,9 @@ class TrafficEnv(gym.Env):
         self.waiting = DeviceView(lambda: eng.waiting[0])
         self.passed_dst = DeviceView(lambda: eng.passed_dst[0], dtype=np.bool_)
         self._spawn_counts = np.zeros((1, max(1, eng.n_entry)), np.int32)
-        # read-backs go through pinned mirrors: one stream synchronisation per step / per decision
-        tail = [eng.n_trips] if self._validate else []
-        self._mirror = eng.host_mirror(eng.obs, eng.rewards, eng.done, *tail)
+        # read-backs go through pinned mirrors of packed buffers: ONE device-to-host copy and one stream
+        # synchronisation per step (two per fused decision), one host-to-device copy for the inputs
+        self._mirror = eng.out_mirror()
         self._mirror_rep = None
         self._trips_seen = 0
 
@@ -267,15 +267,15 @@ class TrafficEnv(gym.Env):
         roads = self._spawns()
         self.generated_cars += len(roads)
         counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._spawn_counts[0])
-        eng.set_spawns(counts=self._spawn_counts)
         # `current_phase[:] = action` / logical_xor semantics: any dtype, truthiness for the change
         act = np.asarray(action)
         if flag('learn_switch', False):
             act = (act != 0)
-        eng.set_actions(act.astype(np.int32).reshape(1, -1))
-        eng.step(1)
+        eng.stage_inputs(act.astype(np.int32), self._spawn_counts)
+        first = eng.tick
+        eng.step(1, update_done=False)
         self.steps += 1
-        overflowed = self._pull()
+        overflowed = self._pull(first)
         return self.obs, self.rewards, overflowed, None
 
     def repeat(self, action, n_ticks):
@@ -296,24 +296,23 @@ class TrafficEnv(gym.Env):
             roads = self._spawns()
             made.append(len(roads))
             counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._rep_counts[t, 0])
-        eng.set_spawns(counts=self._rep_counts, per_tick=True)
         act = np.asarray(action)
         if flag('learn_switch', False):
             act = (act != 0)
-        eng.set_actions(act.astype(np.int32).reshape(1, -1))
+        eng.stage_inputs(act.astype(np.int32), self._rep_counts, per_tick=True)
         first = eng.tick
-        aobs, arew, adone = eng.agent_step(n, remi=False)
+        eng.agent_step(n, remi=False)
         if self._mirror_rep is None:
-            tail = [eng.n_trips] if self._validate else []
-            self._mirror_rep = eng.host_mirror(aobs, arew, adone, eng.obs, eng.rewards, eng.done_tick, *tail)
-        got = self._mirror_rep.pull()
-        total_obs, total_reward = got[0][0].copy(), got[1][0].copy()
-        done = bool(got[2][0])
+            self._mirror_rep = eng.agent_mirror()
+        arep = self._mirror_rep.start()
+        got = self._mirror.pull()                 # (one synchronisation completes both copies)
+        total_obs, total_reward = arep["aobs"][0].copy(), arep["areward"][0].copy()
+        done = bool(got["done"][0])
         ran = n
         if done:
             # the loop broke after the overflowing tick: un-draw the arrivals of the ticks that
             # never ran and put the device clock where `steps` is
-            ran = int(got[5][0]) - first
+            ran = int(got["done_tick"][0]) - first
             if ran < n:
                 self._rewind_spawner(mark)
                 for _ in range(ran):
@@ -321,10 +320,10 @@ class TrafficEnv(gym.Env):
                 eng.set_tick(first + ran)
         self.steps += ran
         self.generated_cars += sum(made[:ran])
-        self.obs[:] = got[3][0]
-        self.rewards[:] = got[4][0]
+        self.obs[:] = got["obs"][0]
+        self.rewards[:] = got["rewards"][0]
         if self._validate:
-            self._collect_trips(int(got[6][0]))
+            self._collect_trips(int(got["n_trips"][0]))
         return total_obs, total_reward, done
 
     def _mark_spawner(self):
@@ -345,15 +344,18 @@ class TrafficEnv(gym.Env):
             else:
                 s._started, s._gap, s._i = inner
 
-    def _pull(self):
-        """Refresh the live host buffers (obs, rewards) from the device; returns the done flag.  In
+    def _pull(self, since_tick=None):
+        """Refresh the live host buffers (obs, rewards) from the device; returns the done flag (with
+        `since_tick`: an overflow in a tick >= since_tick, from the env's overflow stamp).  In
         validate mode also collects the trip times recorded since the last pull."""
         got = self._mirror.pull()
-        self.obs[:] = got[0][0]
-        self.rewards[:] = got[1][0]
+        self.obs[:] = got["obs"][0]
+        self.rewards[:] = got["rewards"][0]
         if self._validate:
-            self._collect_trips(int(got[3][0]))
-        return bool(got[2][0])
+            self._collect_trips(int(got["n_trips"][0]))
+        if since_tick is not None:
+            return bool(got["done_tick"][0] > since_tick)
+        return bool(got["done"][0])
 
     def _collect_trips(self, n_now):
         seen = getattr(self, '_trips_seen', 0)

@@ -327,6 +327,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": load_pmc_traffic(a.config, kernel) if E == c["envs"] else None,
                          "algorithmic_bytes_per_launch": move_bytes, "launch_ms": move_ms,
+                         # (k_res runs all the ticks of a tfx_step call in one launch: the figures above
+                         # are per TICK of that launch)
+                         "ticks_per_launch": (GATHER_EVERY if gather is not None else K) if kernel == "k_res" else 1,
                          "launches_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,
                          "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS

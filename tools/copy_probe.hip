@@ -112,6 +112,102 @@ __global__ __launch_bounds__(256) void k_model(f2 *__restrict__ a, int *__restri
   }
 }
 
+// k_model_g: the same stream in k_rw's 8-row shape - the G loads of the NEXT group issued back to back
+// at the top of a group, the group computed in registers, its G stores issued back to back - with
+// k_move_t's ragged road lengths, per-road words and arithmetic
+template <int G, bool RAGGED, bool WORDS, bool MATH>
+__global__ __launch_bounds__(256) void k_model_g(f2 *__restrict__ a, int *__restrict__ words, size_t n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * 4;
+  for (size_t t = wave; t < n_tiles; t += nwaves) {
+    f2 *col = a + t * 4096 + lane;
+    unsigned h = (unsigned)(t * 64 + lane) * 2654435761u;
+    int n = RAGGED ? 40 + (int)((h >> 8) % 17u) : 48;
+    float acc = 0.f;
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+      int s0 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s0 += w[q * n_tiles * 64];
+      n += (s0 & 0);
+      acc = (float)(s0 & 1);
+    }
+    int kmax = n;
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(kmax, off, 64);
+      kmax = o > kmax ? o : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    f2 pf[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) pf[u] = (u < n) ? __builtin_nontemporal_load(col + (size_t)u * 64) : f2{0, 0};
+    float px = 1e9f, pv = 0.f;
+    for (int k0 = 0; k0 < kmax; k0 += G) {
+      f2 cur[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) cur[u] = pf[u];
+      if (k0 + G < kmax) {
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+          pf[u] = (k0 + G + u < n) ? __builtin_nontemporal_load(col + (size_t)(k0 + G + u) * 64) : f2{0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const f2 c = cur[u];
+        if (k0 + u < n) {
+          f2 o = c;
+          if (MATH) {
+            float s = px - c.x - 4.f, q = c.y * 0.072f;
+            float st = 1.f + c.y * 2.f + c.y * (c.y - pv) * 0.1178f;
+            float r = st / (s + 1e-8f);
+            float dv = 3.f * (1.f - q * q * q * q - r * r);
+#pragma unroll
+            for (int z = 0; z < 12; ++z) dv = dv * 0.999f + 0.001f * r;
+            o.x = c.x + fmaxf(0.f, 0.5f * c.y + 0.125f * dv);
+            o.y = fmaxf(0.f, c.y + 0.5f * dv);
+            px = c.x;
+            pv = c.y;
+          } else {
+            o.x = c.x * 1.0001f + 0.5f;
+          }
+          cur[u] = o;
+          acc += o.x;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (k0 + u < n) __builtin_nontemporal_store(cur[u], col + (size_t)(k0 + u) * 64);
+    }
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) w[(8 + q) * n_tiles * 64] = (int)acc + q;
+    }
+  }
+}
+
+#define MODELG(label, G, RG, WD, MA, grid)                                                         \
+  do {                                                                                            \
+    const size_t n_tiles = bytes / 32768;                                                         \
+    hipEvent_t s, e;                                                                              \
+    hipEventCreate(&s);                                                                           \
+    hipEventCreate(&e);                                                                           \
+    for (int i = 0; i < 2; ++i)                                                                   \
+      hipLaunchKernelGGL((k_model_g<G, RG, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(s);                                                                            \
+    for (int i = 0; i < 10; ++i)                                                                  \
+      hipLaunchKernelGGL((k_model_g<G, RG, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(e);                                                                            \
+    hipEventSynchronize(e);                                                                       \
+    float ms = 0;                                                                                 \
+    hipEventElapsedTime(&ms, s, e);                                                               \
+    ms /= 10;                                                                                     \
+    printf("model %-38s grid %5d: %.3f ms\n", label, grid, ms);                                   \
+    hipEventDestroy(s);                                                                           \
+    hipEventDestroy(e);                                                                           \
+  } while (0)
+
 #define MODEL(label, U, RG, SH, WD, MA, grid)                                                      \
   do {                                                                                            \
     const size_t n_tiles = bytes / 32768;                                                         \
@@ -184,6 +280,14 @@ int main(int argc, char **argv) {
     MODEL("48 rows + per-road words", 4, false, false, true, false, g);
     MODEL("48 rows + arithmetic", 4, false, false, false, true, g);
     MODEL("ragged + words + arithmetic", 4, true, false, true, true, g);
+    MODEL("ragged + words + arithmetic, 8 rolling", 8, true, false, true, true, g);
+    MODELG("grouped 8: 48 rows per road", 8, false, false, false, g);
+    MODELG("grouped 8: ragged tails", 8, true, false, false, g);
+    MODELG("grouped 8: ragged + words + arithmetic", 8, true, true, true, g);
+    MODELG("grouped 4: ragged + words + arithmetic", 4, true, true, true, g);
+    MODELG("grouped 16: ragged + words + arithmetic", 16, true, true, true, g);
+    MODELG("grouped 8: ragged + words + arith, 4/CU", 8, true, true, true, cu * 4);
+    MODELG("grouped 8: ragged + words + arith, 6/CU", 8, true, true, true, cu * 6);
   }
   hipFree(a);
   hipFree(b);

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh <outdir under gpurun_out>
+# kernel-trace --stats and the PMC passes (FETCH_SIZE and WRITE_SIZE in passes of their own, as the
+# guide prescribes; SQ counters in a third) for cfg2, cfg1, cfg4, plus the un-profiled bench lines.
+# tools/pmc_summary.py condenses the directories into profiles/.
+set -u
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-prof}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+prof() {  # name, rocprof args..., -- bench args
+  local name=$1; shift
+  local rargs=(); while [ "$1" != "--" ]; do rargs+=("$1"); shift; done; shift
+  rocprofv3 "${rargs[@]}" -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $O/$name.log 2>&1 || echo "FAILED $name"
+  echo "done $name"
+}
+for cfg in cfg2 cfg1 cfg4; do
+  prof ${cfg}_kt --kernel-trace --stats -- --config $cfg
+  prof ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -- --config $cfg
+  prof ${cfg}_write --kernel-trace --pmc WRITE_SIZE -- --config $cfg
+  prof ${cfg}_sq --kernel-trace --pmc $SQ -- --config $cfg
+done
+TFX_MOVE_VARIANT=104 prof cfg2_t2_sq --kernel-trace --pmc $SQ -- --config cfg2
+TFX_MOVE_VARIANT=104 prof cfg2_t2_kt --kernel-trace --stats -- --config cfg2
+TFX_RESIDENT=0 prof cfg1_pertick_kt --kernel-trace --stats -- --config cfg1
+cd $R
+for cfg in cfg2 cfg1 cfg0 cfg4; do
+  python3 bench.py --config $cfg --steps 200 --warmup 20 $( [ $cfg = cfg2 ] || echo --no-cpu-baseline ) > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  echo "bench $cfg: $(python3 -c "import json;d=json.load(open('$O/bench_$cfg.json'));print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])")"
+done
+TFX_RESIDENT=0 python3 bench.py --config cfg1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg1_pertick.json 2>/dev/null
+python3 bench.py --config cfg1 --envs 4096 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg1_4096.json 2>/dev/null
+python3 bench.py --config cfg2 --envs 256 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_256.json 2>/dev/null
+python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg2_32768.json 2>/dev/null
+( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt
+echo finished

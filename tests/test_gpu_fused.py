@@ -35,8 +35,8 @@ def engine_with(env, E, layout="transposed", planes=2, **cfg):
     return eng
 
 
-def fused_engine(E, epb=2, **cfg):
-    eng = engine_with({"TFX_RESIDENT": "1", "TFX_RES_EPB": str(epb)}, E, **cfg)
+def fused_engine(E, epb=2, lpr=2, **cfg):
+    eng = engine_with({"TFX_RESIDENT": "1", "TFX_RES_EPB": str(epb), "TFX_RES_LPR": str(lpr)}, E, **cfg)
     assert eng.fused_ticks() == (0, True)
     return eng
 
@@ -55,8 +55,8 @@ def pertick_engine(E, **cfg):
 def test_fused_random_states_vs_oracle(m, n, C, length, sorted_x, layout):
     rng = np.random.RandomState(4321 + C + int(sorted_x))
     E, T = 5, 7
-    eng = fused_engine(E, epb=1 + C % 3, layout=layout, planes=3 if layout == "ring" else 2, m=m, n=n,
-                       length=length, capacity=C, rate=0.5)
+    eng = fused_engine(E, epb=1 + C % 3, lpr=1 + int(sorted_x), layout=layout, planes=3 if layout == "ring" else 2,
+                       m=m, n=n, length=length, capacity=C, rate=0.5)
     orc = oracle_like(eng)
     ran = 0
     for trial in range(5):
@@ -87,8 +87,8 @@ def test_fused_equals_tick_by_tick_on_device_rules():
     60 single ticks == the same with fusing disabled; counters and done flags included."""
     E, T = 9, 60
     cfg = dict(m=4, n=4, length=200.0, capacity=34, rate=0.5)
-    a = fused_engine(E, epb=4, **cfg)
-    b = fused_engine(E, epb=1, **cfg)
+    a = fused_engine(E, epb=4, lpr=2, **cfg)
+    b = fused_engine(E, epb=1, lpr=1, **cfg)
     c = pertick_engine(E, **cfg)
     x, v, leading, lastcar = wl.prefill_one_env(4, 4, 200.0, 34, 24, 8.0)
     for eng in (a, b, c):

@@ -37,11 +37,12 @@ def car_layout(request):
 # ... and through both step paths: the LDS-resident multi-tick kernel k_res (what small envs get by
 # default, packing 3 envs per workgroup so wavefronts straddle env boundaries) and the per-tick
 # streaming kernels (TFX_RESIDENT=0: what big envs get)
-@pytest.fixture(params=["resident", "pertick"], autouse=True)
+@pytest.fixture(params=["resident", "resident1", "pertick"], autouse=True)
 def step_path(request, monkeypatch):
-    if request.param == "resident":
+    if request.param.startswith("resident"):
         monkeypatch.setenv("TFX_RESIDENT", "1")
         monkeypatch.setenv("TFX_RES_EPB", "3")
+        monkeypatch.setenv("TFX_RES_LPR", "1" if request.param == "resident1" else "2")   # lanes per road
     else:
         monkeypatch.setenv("TFX_RESIDENT", "0")
     yield request.param

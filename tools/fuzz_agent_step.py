@@ -1,6 +1,6 @@
 """Randomised differential test of the fused agent step (tfx_agent_step: Repeater + Remi on the device,
 HIP graph replay) against the same wrappers emulated tick by tick on single-env oracles - random
-grid, capacity, batch, layout, decision length, periodic arrival density, with and without Remi,
+grid, capacity, batch, layout, step path (k_res / per-tick kernels), decision length, periodic arrival density, with and without Remi,
 including decisions cut short by an overflow.  FUZZ_SECS (default 300)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +19,9 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     E = int(rng.choice([1, 3, 7, 33]))
     layout = str(rng.choice(["ring", "transposed"]))
     remi = bool(rng.randint(2)); T = int(rng.choice([2, 5, 10])); period = int(rng.choice([1, 2, 5, 9]))
+    os.environ["TFX_RESIDENT"] = str(int(rng.randint(3) > 0))     # the LDS-resident k_res (2 in 3) | per-tick kernels
+    os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 4])))
+    os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))
     eng = TfxEngine(m, nn, L, C, n_envs=E, planes=2 if layout == "transposed" else 3, layout=layout)
     orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
     ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)

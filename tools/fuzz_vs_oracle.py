@@ -26,7 +26,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_KINDS", "TFX_MOVE_VARIANT")}
+    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -55,6 +55,7 @@ def _run(rng, seed, LIMIT):
         if layout == "transposed" and mv: os.environ["TFX_MOVE_VARIANT"] = str(mv)
         os.environ["TFX_RESIDENT"] = "1" if mode == 1 else "0"      # LDS-resident multi-tick kernel | per-tick kernels
         os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))
+        os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))    # lanes per road of k_res
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
         eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)

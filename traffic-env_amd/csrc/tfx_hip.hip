@@ -64,6 +64,7 @@ struct tfx_handle_s {
   int tiles_per_env = 0;      // G: 64-slot tiles one env occupies in the transposed layout
   // k_res (tfx_resident.hpp): whole envs resident in LDS for all the ticks of a call
   int res_epb = 0;            // envs per workgroup; 0 = the envs do not fit / disabled (TFX_RESIDENT=0)
+  int res_lpr = 1;            // lanes per road (1 or 2)
   int res_threads = 0;
   size_t res_lds = 0;
   int res_min_ticks = 1;      // calls shorter than this take the per-tick kernels (TFX_RES_MIN_TICKS)
@@ -336,39 +337,59 @@ int launch_inputs(tfx_handle h, hipStream_t st) {
   return TFX_OK;
 }
 
-// k_res: how many envs a workgroup takes (0 = not applicable).  Limits: one lane per road and at most
-// RES_MAX_THREADS lanes; the rings of the workgroup's envs in the LDS a workgroup may have (asked from the
-// runtime with hipFuncSetAttribute: 160 KB per CU on gfx950).
+// k_res: lanes per road and envs per workgroup (res_epb = 0: not applicable).  Limits: at most
+// RES_MAX_THREADS lanes; the rings of the workgroup's envs in the LDS a workgroup may have (asked from
+// the runtime with hipFuncSetAttribute: 160 KB per CU on gfx950).  Two lanes per road whenever one env
+// fits that way (the walk of a road is the tick's critical path; TFX_RES_LPR=1 forces one).
+template <int LPR, bool W>
+bool res_try(tfx_handle h, int epb) {
+  const Dev &d = h->d;
+  const int threads = (LPR * epb * d.R + 63) / 64 * 64;
+  if (threads > RES_MAX_THREADS) return false;
+  const size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, W);
+  if (lds > (size_t)160 * 1024) return false;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<LPR, W>)),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;  // the runtime does not grant that much LDS
+  }
+  h->res_lpr = LPR;
+  h->res_epb = epb;
+  h->res_threads = threads;
+  h->res_lds = lds;
+  return true;
+}
+
 template <bool W>
 int res_configure(tfx_handle h) {
   const Dev &d = h->d;
   h->res_epb = 0;
   if (const char *rv = getenv("TFX_RESIDENT")) if (atoi(rv) == 0) return TFX_OK;
   if (const char *mt = getenv("TFX_RES_MIN_TICKS")) h->res_min_ticks = atoi(mt);
-  if (d.R > RES_MAX_THREADS) return TFX_OK;
-  const size_t lds_cap = 160 * 1024;
-  int want = (d.E + h->n_cu - 1) / h->n_cu;  // spread the envs over the chip first
-  if (const char *ev = getenv("TFX_RES_EPB")) want = atoi(ev);
-  if (want < 1) want = 1;
-  if (want > d.E) want = d.E;
-  int epb = 0, threads = 0;
-  size_t lds = 0;
-  for (int k = 1; k <= want; ++k) {
-    const int th = (k * d.R + 63) / 64 * 64;
-    const size_t b = res_lds_bytes(th, d.C, k, d.I, W);
-    if (th > RES_MAX_THREADS || b > lds_cap) break;
-    epb = k; threads = th; lds = b;
+  int lpr_max = 2;
+  if (const char *lv = getenv("TFX_RES_LPR")) lpr_max = atoi(lv) == 1 ? 1 : 2;
+  const char *ev = getenv("TFX_RES_EPB");
+  for (int lpr = lpr_max; lpr >= 1; --lpr) {
+    auto fits = [&](int epb) { return lpr == 2 ? res_try<2, W>(h, epb) : res_try<1, W>(h, epb); };
+    if (!fits(1)) continue;  // (leaves the one-env configuration in place)
+    if (ev) {
+      int want = atoi(ev) < 1 ? 1 : atoi(ev);
+      if (want > d.E) want = d.E;
+      while (want > 1 && !fits(want)) --want;
+      return TFX_OK;
+    }
+    // two lanes per road: one env per workgroup measured best at every batch size (cfg1 x 1024: a
+    // 10-tick call 100 us against 172 with two envs, x 4096: 403 against 533 with three) - fewer
+    // wavefronts meet at each barrier.  One lane per road: 80-lane envs leave wavefronts half empty, so
+    // pack envs: the smallest number of equal rounds over the chip, E / (CUs * b) for b = 1, 2, ...
+    if (lpr == 2) return TFX_OK;
+    for (int b = 1; b <= 64; ++b) {
+      const int epb = (d.E + h->n_cu * b - 1) / (h->n_cu * b);
+      if (epb <= 1 || fits(epb)) break;
+    }
+    return TFX_OK;
   }
-  if (epb == 0) return TFX_OK;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<W>)),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return TFX_OK;  // the runtime does not grant that much LDS: per-tick kernels
-  }
-  h->res_epb = epb;
-  h->res_threads = threads;
-  h->res_lds = lds;
   return TFX_OK;
 }
 
@@ -378,9 +399,15 @@ bool res_usable(tfx_handle h, int n_ticks) {
   return h->res_epb > 0 && !h->poisson && !h->d.validate && n_ticks >= h->res_min_ticks;
 }
 
-int launch_res(tfx_handle h, int n_ticks, hipStream_t st) {
+int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi = 0, float *aobs = nullptr,
+               float *areward = nullptr, uint8_t *adone = nullptr) {
   const Dev &d = h->d;
   ResArgs a;
+  a.tail = tail;
+  a.remi = remi;
+  a.aobs = aobs;
+  a.areward = areward;
+  a.adone = adone;
   a.epb = h->res_epb;
   a.n_ticks = n_ticks;
   a.greedy_spacing = h->greedy ? h->greedy_spacing : 0;
@@ -388,8 +415,14 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st) {
   const int grid = (d.E + h->res_epb - 1) / h->res_epb;
   a.own_clock = grid == 1 ? 1 : 0;
   h->step_kernel = "k_res";
-  if (d.w) hipLaunchKernelGGL(k_res<true>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
-  else hipLaunchKernelGGL(k_res<false>, dim3(grid), dim3(h->res_threads), h->res_lds, st, d, a);
+  const dim3 g(grid), b(h->res_threads);
+  if (h->res_lpr == 2) {
+    if (d.w) hipLaunchKernelGGL((k_res<2, true>), g, b, h->res_lds, st, d, a);
+    else hipLaunchKernelGGL((k_res<2, false>), g, b, h->res_lds, st, d, a);
+  } else {
+    if (d.w) hipLaunchKernelGGL((k_res<1, true>), g, b, h->res_lds, st, d, a);
+    else hipLaunchKernelGGL((k_res<1, false>), g, b, h->res_lds, st, d, a);
+  }
   HIPCHK(hipGetLastError());
   if (!a.own_clock) {  // every workgroup reads the clock at its start: it moves in a launch of its own
     hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, d, n_ticks);
@@ -415,16 +448,23 @@ namespace {
 int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
                    hipStream_t st) {
   Dev &d = h->d;
+  const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
+  if (res_usable(h, n_ticks)) {
+    // every tick of the decision AND its tail (remi, observation, rewards, done flags) in one launch
+    d.agent_mode = 1;
+    d.accum_rewards = remi ? 0 : 1;
+    const int rc = launch_res(h, n_ticks, st, 1, remi, aobs, areward, adone);
+    d.agent_mode = keep_mode;
+    d.accum_rewards = keep_acc;
+    if (rc == TFX_OK) h->fused_ticks += n_ticks;
+    return rc;
+  }
   hipLaunchKernelGGL(k_agent_begin, dim3(1), dim3(1), 0, st, d, const_cast<int *>(d.agent_first));
   HIPCHK(hipGetLastError());
-  const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
   d.agent_mode = 1;
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
-  if (res_usable(h, n_ticks)) {
-    rc = launch_res(h, n_ticks, st);  // every tick of the decision in one launch, the cars in LDS
-    if (rc == TFX_OK) h->fused_ticks += n_ticks;
-  } else {
+  {
     for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
       rc = launch_inputs(h, st);
       if (rc == TFX_OK) rc = launch_move(h, t, st);

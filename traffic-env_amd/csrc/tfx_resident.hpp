@@ -4,7 +4,12 @@
 // The per-tick kernels stream every car through HBM twice per tick and pay two launches per tick;
 // for small grids that is all latency (round 1: cfg1 x 1024 envs at 0.18 of the HBM roofline, 38 us
 // per tick of which the cars need 3).  Here a workgroup owns `epb` whole envs for the whole call:
-//   * one lane per road (lanes = epb * R, packed across env boundaries so wavefronts stay full);
+//   * LPR = 1 or 2 lanes per road (lanes = LPR * epb * R, packed across env boundaries so wavefronts
+//     stay full).  With two lanes the road's cars split in halves - the Jacobi update needs only OLD
+//     neighbours, so the second lane starts from the OLD state of the car in front of its half (read
+//     before the first lane, which sits next to it in the same wavefront, overwrites it) - and the
+//     walk, the tick's critical path, is half as long; pops, counts and the tail meet through a lane
+//     shuffle (the second half's pop prefix counts only if every car of the first half popped);
 //   * the cars sit in LDS in the REFERENCE's ring layout - ring[slot][lane], slots 1..C-1, the same
 //     leading / lastcar indices as traffic_env.py - so a tick moves no car that did not move: the IDM
 //     walk (k_move_t's lane-per-road chain: the leader of car k is the lane's previous car, OLD
@@ -35,26 +40,34 @@ struct ResArgs {
   int greedy_spacing;  // > 0: the greedy controller decides in the kernel (algorithms/greedy.py:14-16)
   int *greedy_act;     // [E][I] held greedy actions (in/out)
   int own_clock;       // single-workgroup launch: the kernel advances the device clock itself
+  // the rest of an agent decision (tfx_agent_step), folded into the kernel's tail when `tail` is set:
+  // remi_reward() (traffic_env.py:64-78) if `remi`, the Repeater's observation (traffic_test.py:48-53),
+  // the decision's rewards and done flags - what k_remi, k_agent_obs, a copy and k_done_since do after
+  // the per-tick kernels
+  int tail, remi;
+  float *aobs, *areward;  // [E][2r+I], [E][I] (may be null)
+  uint8_t *adone;         // [E] (may be null)
 };
 
 constexpr int RES_KH = 2;  // popped cars copied per handoff round
 constexpr int RES_MAX_THREADS = 512;  // lanes (= roads) per workgroup: 8 wavefronts, up to 256 VGPRs each
 
-// bytes of dynamic LDS for T lanes
-__host__ __device__ inline size_t res_lds_bytes(int T, int C, int epb, int I, bool W) {
+// bytes of dynamic LDS for Tr road columns (Tr = lanes / lanes-per-road)
+__host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, bool W) {
   const size_t ns = (size_t)(C - 1);
-  size_t b = ns * T * sizeof(float2);
-  if (W) b += ns * T * sizeof(float);
-  b += (size_t)T * 8 * 4;                // ld, lc, kpop, cnt, tail, passed, ovf, ovfsp
+  size_t b = ns * Tr * sizeof(float2);
+  if (W) b += ns * Tr * sizeof(float);
+  b += (size_t)Tr * 8 * 4;               // ld, lc, kpop, cnt, tail, passed, ovf, ovfsp
   b += (size_t)epb * I * (2 * 8 + 4 + 4 + 4);  // light[2], rew, pdst, act
   b += (size_t)epb * 2 * 4 + 16;         // ovftick, fartick, maxpop[2]
   return (b + 15) & ~(size_t)15;
 }
 
-template <bool W>
+template <int LPR, bool W>
 __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResArgs a) {
+  static_assert(LPR == 1 || LPR == 2, "one or two lanes per road");
   extern __shared__ __align__(16) unsigned char res_smem[];
-  const int T = blockDim.x, C = d.C, NS = C - 1, R = d.R, I = d.I;
+  const int T = blockDim.x / LPR, C = d.C, NS = C - 1, R = d.R, I = d.I;  // T: road columns of the workgroup
   const int epb = a.epb;
   float2 *ring = reinterpret_cast<float2 *>(res_smem);
   float *ringw = reinterpret_cast<float *>(ring + (size_t)NS * T);
@@ -70,7 +83,9 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   int *s_fartick = s_ovftick + epb;          // [epb] tick + 1 of the last tick that needs the serial loop
   int *s_maxpop = s_fartick + epb;           // [2] most cars any road popped, by tick parity
 
-  const int t = threadIdx.x;
+  const int h = LPR == 2 ? (int)(threadIdx.x & 1) : 0;  // which half of the road's cars this lane walks
+  const bool hA = h == 0;                                // the road's first lane also does everything per road
+  const int t = LPR == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x;  // the road's column
   const int env_l = t / R, e = t - env_l * R;
   const int env = blockIdx.x * epb + env_l;
   const bool valid = env_l < epb && env < d.E;
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   const int pe = valid ? d.pred[e] : -1;
   const int nx = train ? d.nexts[e] : -1;
   const int tn = t - e + nx, tp = t - e + pe;  // lanes of the next / previous road
-  const bool des = train && dir == 0;          // this lane also keeps intersection `isec`
+  const bool des = train && dir == 0 && hA;    // this lane also keeps intersection `isec`
   auto RG = [&](int slot, int lane) -> float2 & { return ring[(size_t)(slot - 1) * T + lane]; };
   auto RW = [&](int slot, int lane) -> float & { return ringw[(size_t)(slot - 1) * T + lane]; };
 
@@ -95,21 +110,24 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     ld = d.leading[id];
     lc = d.lastcar[id];
     const int n = ring_count(ld, lc, C);
-    int slot = ld;
+    const int head = wrap1(ld + 1, C);
     if (d.layout == 1) {
       const size_t col = tcol(d, env, e);
-      for (int k = 0; k < n; ++k) {
-        slot = wrap1(slot + 1, C);
+      for (int k = h; k < n; k += LPR) {  // (the road's lanes share the copy)
+        const int slot = ring_adv(head, k, C);
         RG(slot, t) = d.xv[col + (size_t)k * 64];
         if (W) RW(slot, t) = d.w[col + (size_t)k * 64];
       }
     } else {
-      for (int k = 0; k < n; ++k) {
-        slot = wrap1(slot + 1, C);
+      for (int k = h; k < n; k += LPR) {
+        const int slot = ring_adv(head, k, C);
         RG(slot, t) = d.xv[(size_t)id * C + slot];
         if (W) RW(slot, t) = d.w[(size_t)id * C + slot];
       }
     }
+  }
+  if (valid && hA) {
+    const int n = ring_count(ld, lc, C);
     s_ld[t] = ld;
     s_lc[t] = lc;
     s_cnt[t] = n;
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       s_fartick[env_l] = 0;
     }
   }
-  if (t == 0) s_maxpop[0] = s_maxpop[1] = 0;
+  if (threadIdx.x == 0) s_maxpop[0] = s_maxpop[1] = 0;
   __syncthreads();
 
   int wait_acc = 0, det = 0;
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
         s_act[li] = (s_cnt[b] + s_cnt[b + I] - s_cnt[b + 2 * I] - s_cnt[b + 3 * I] < 0) ? 1 : 0;
       }
     }
-    if (run) {
+    if (run && hA) {
       ld = s_ld[t];
       lc = s_lc[t];
       const int n_old = ring_count(ld, lc, C);
@@ -208,7 +226,18 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     }
     // ---- move_cars (:187-212): the lane walks its road from the head, leader chain in registers ---
     {
-      int kmax = run ? n_tot : 0;
+      if (LPR == 2) {  // what the road's first lane worked out, for the second one
+        const int src = (int)(threadIdx.x & 62u);
+        n_tot = __shfl(n_tot, src, 64);
+        ld = __shfl(ld, src, 64);
+        lc = __shfl(lc, src, 64);
+        xL = __shfl(xL, src, 64);
+      }
+      // this lane's share of the road: cars [my_k0, my_k0 + my_n)
+      const int n_first = LPR == 2 ? (n_tot + 1) >> 1 : n_tot;
+      const int my_k0 = hA ? 0 : n_first;
+      const int my_n = run ? (hA ? n_first : n_tot - n_first) : 0;
+      int kmax = my_n;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(kmax, off, 64);
@@ -216,8 +245,17 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       }
       kmax = __builtin_amdgcn_readfirstlane(kmax);
       float xprev = xL, vprev = 0.0f, llv = 0.0f;
+      const int head = wrap1(ld + 1, C);
+      if (LPR == 2 && !hA && my_n > 0) {
+        // the second half follows the last car of the first half: its OLD state, read here - before the
+        // neighbouring lane (same wavefront, so in program order) rewrites that slot
+        const float2 lead = RG(ring_adv(head, n_first - 1, C), t);
+        xprev = lead.x;
+        vprev = lead.y;
+        llv = d.car_l;
+      }
       int n_wait = 0, n_det = 0;
-      bool open = true;
+      bool open = true;  // (second half: provisionally - it counts only if the whole first half popped)
       // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
       const int kq = (ld > lc) ? C - 1 - ld : 0x7fffffff;
       // Groups of G cars computed together, as in k_move_t2: the kernel runs one or two wavefronts
@@ -228,13 +266,13 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       // zeros; only the ring writes and the counters are predicated.
       constexpr int G = 4;
       const bool fast_ok = d.fastdiv && d.fastmax;
-      int slot = wrap1(ld + 1, C);
+      int slot = ring_adv(head, my_k0, C);
       int psl[G];
       float2 pf[G];
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         psl[u] = slot;
-        pf[u] = (u < n_tot) ? RG(slot, t) : make_float2(0.0f, 0.0f);
+        pf[u] = (u < my_n) ? RG(slot, t) : make_float2(0.0f, 0.0f);
         slot = wrap1(slot + 1, C);
       }
       for (int k0 = 0; k0 < kmax; k0 += G) {
@@ -249,7 +287,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
 #pragma unroll
           for (int u = 0; u < G; ++u) {
             psl[u] = slot;
-            pf[u] = (k0 + G + u < n_tot) ? RG(slot, t) : make_float2(0.0f, 0.0f);
+            pf[u] = (k0 + G + u < my_n) ? RG(slot, t) : make_float2(0.0f, 0.0f);
             slot = wrap1(slot + 1, C);
           }
         }
@@ -291,11 +329,11 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
         llv = d.car_l;
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-          const int k = k0 + u;
-          const bool act = k < n_tot;
+          const int k = my_k0 + k0 + u;  // the car's index on its road
+          const bool act = k0 + u < my_n;
           if (act) RG(csl[u], t) = make_float2(xn[u], vn[u]);
           const bool pop = open && act && (xn[u] > d.length);  // the while loop of :123
-          open = pop;
+          open = act ? pop : open;  // (rows past the lane's share leave it as it is: the halves combine on it)
           kpop += pop ? 1 : 0;
           far = far || (pop && ((xn[u] - d.length) > d.length));
           const float wq = (k >= kq) ? xn[u] : vn[u];
@@ -304,7 +342,21 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
           tail_x = act ? xn[u] : tail_x;
         }
       }
-      if (run) {
+      if (LPR == 2) {  // the halves meet in the road's first lane
+        const int kpop_b = __shfl_xor(kpop, 1, 64), wait_b = __shfl_xor(n_wait, 1, 64), det_b = __shfl_xor(n_det, 1, 64);
+        const int far_b = __shfl_xor((int)far, 1, 64), n_b = __shfl_xor(my_n, 1, 64);
+        const float tail_b = __shfl_xor(tail_x, 1, 64);
+        if (hA) {
+          if (open) {  // every car of the first half left: the pop prefix runs on into the second half
+            kpop += kpop_b;
+            far = far || (far_b != 0);
+          }
+          n_wait += wait_b;
+          n_det += det_b;
+          if (n_b > 0) tail_x = tail_b;
+        }
+      }
+      if (run && hA) {
         if (train) {
           if (n_tot > 0) {
             wait_acc += n_wait;
@@ -325,15 +377,15 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     __syncthreads();  // B1: every ring holds its post-move cars, pops are published
 
     // ---- advance_finished_cars (:117-135) -------------------------------------------------------
-    if (t == 0) s_maxpop[par ^ 1] = 0;
+    if (threadIdx.x == 0) s_maxpop[par ^ 1] = 0;
     const bool serial_env = valid && s_fartick[env_l] == tick + 1;
     const int rounds = (s_maxpop[par] + RES_KH - 1) / RES_KH;
-    const bool pull = run && !serial_env;
+    const bool pull = run && !serial_env && hA;
     const int ld_post = ring_adv(ld, kpop, C);
     const int k_p = (pull && pe >= 0) ? s_kpop[tp] : 0;
     const int ld_seen = (pe < e) ? ld : ld_post;  // p's pushes see leading[e] before e's own pops iff p < e
     int ovf = 0;
-    if (serial_env && e == 0 && run) {
+    if (serial_env && e == 0 && run && hA) {
       // literal single-lane loop for this env (a handed-off car is itself beyond the next road's end)
       const int b = t;  // lane of road 0
       float *rew = s_rew + (size_t)env_l * I;
@@ -441,7 +493,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       for (int j = 0; j < sum; ++j) rw -= d.ovf_pen;
       s_rew[li] = rw;
     }
-    if (valid && e == 0 && run && !serial_env && s_ovftick[env_l] == tick + 1) d.done_tick[env] = tick + 1;
+    if (valid && e == 0 && hA && run && !serial_env && s_ovftick[env_l] == tick + 1) d.done_tick[env] = tick + 1;
     // (no barrier here: what the next tick reads before its first barrier - s_cnt / s_tail of the next
     // road, the light words of the other parity, the overflow stamps - was written before B3)
   }
@@ -452,23 +504,25 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     ld = s_ld[t];
     lc = s_lc[t];
     const int n = s_cnt[t];
-    int slot = ld;
+    const int head = wrap1(ld + 1, C);
     if (d.layout == 1) {
       const size_t col = tcol(d, env, e);
-      for (int k = 0; k < n; ++k) {
-        slot = wrap1(slot + 1, C);
+      for (int k = h; k < n; k += LPR) {
+        const int slot = ring_adv(head, k, C);
         d.xv[col + (size_t)k * 64] = RG(slot, t);
         if (W) d.w[col + (size_t)k * 64] = RW(slot, t);
       }
-      if (xL_set) d.leadx[id] = xL;
+      if (xL_set && hA) d.leadx[id] = xL;
     } else {
-      for (int k = 0; k < n; ++k) {
-        slot = wrap1(slot + 1, C);
+      for (int k = h; k < n; k += LPR) {
+        const int slot = ring_adv(head, k, C);
         d.xv[(size_t)id * C + slot] = RG(slot, t);
         if (W) d.w[(size_t)id * C + slot] = RW(slot, t);
       }
-      if (xL_set) d.xv[(size_t)id * C + ld].x = xL;  // the fake leader's x sits in its slot (:133)
+      if (xL_set && hA) d.xv[(size_t)id * C + ld].x = xL;  // the fake leader's x sits in its slot (:133)
     }
+  }
+  if (valid && hA) {
     d.leading[id] = ld;
     d.lastcar[id] = lc;
     d.tailx[id] = s_tail[t];
@@ -476,20 +530,60 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     if (train) {
       ob[e] = s_passed[t];
       if (det_set) ob[d.r + e] = det;
-      if (wait_acc) d.waiting[(size_t)env * d.r + e] += wait_acc;
+      if (!a.tail) {
+        if (wait_acc) d.waiting[(size_t)env * d.r + e] += wait_acc;
+      } else {
+        int *wp = d.waiting + (size_t)env * d.r + e;
+        const int wtot = *wp + wait_acc;
+        s_ovf[t] = wtot;                    // (free after the last tick) for the intersection's lane
+        if (a.remi) *wp = 0;                // remi clears the counters it has read (:77)
+        else if (wait_acc) *wp = wtot;
+        if (a.aobs) {
+          float *ao = a.aobs + (size_t)env * (2 * d.r + I);
+          ao[e] = (float)s_passed[t];
+          ao[d.r + e] = (float)(det_set ? det : ob[d.r + e]);
+        }
+      }
     }
     if (des) {
       const int2 pl = s_light[(size_t)((a.n_ticks - 1) & 1) * epb * I + li];
       ob[2 * d.r + isec] = pl.x;
       ob[2 * d.r + I + isec] = pl.y;
-      d.rewards[(size_t)env * I + isec] = s_rew[li];
-      if (s_pdst[li]) d.passed_dst[(size_t)env * I + isec] = 1;
+      if (!(a.tail && a.remi)) {
+        d.rewards[(size_t)env * I + isec] = s_rew[li];
+        if (s_pdst[li]) d.passed_dst[(size_t)env * I + isec] = 1;
+      }
       if (a.greedy_spacing > 0) a.greedy_act[(size_t)env * I + isec] = s_act[li];
+    }
+    if (a.tail && a.adone && e == 0) a.adone[env] = s_ovftick[env_l] > tick0 ? 1 : 0;
+  }
+  if (a.tail) {
+    __syncthreads();  // the roads' waiting totals are in s_ovf
+    if (valid && des) {
+      const int2 pl = s_light[(size_t)((a.n_ticks - 1) & 1) * epb * I + li];
+      const size_t gi = (size_t)env * I + isec;
+      float rw = s_rew[li];
+      if (a.remi) {  // remi (:64-78) on the decision's final state, as k_remi does
+        const bool pd = d.passed_dst[gi] != 0 || s_pdst[li] != 0;
+        rw = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool green = ((q < 2) ? 1 : 0) != pl.x;
+          const bool waiting = s_ovf[t + q * I] > 0;
+          if (waiting && !green && !pd) rw -= 0.5f;
+          else if (pd && green && !waiting) rw += 0.5f;
+        }
+        d.rewards[gi] = rw;
+        d.passed_dst[gi] = 0;
+      }
+      if (a.areward) a.areward[gi] = rw;
+      if (a.aobs)  // elapsed / 100 * (2 * phase - 1), computed in binary64 like the reference's NumPy expression
+        a.aobs[(size_t)env * (2 * d.r + I) + 2 * d.r + isec] = (float)((double)pl.y / 100.0 * (double)(2 * pl.x - 1));
     }
   }
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
-  if ((t & 63) == 0 && my_updates) veh_add(d.veh, my_updates);
-  if (a.own_clock && t == 0) {  // (one workgroup: nobody else reads the clock during this launch)
+  if ((threadIdx.x & 63) == 0 && my_updates) veh_add(d.veh, my_updates);
+  if (a.own_clock && threadIdx.x == 0) {  // (one workgroup: nobody else reads the clock during this launch)
     *d.tickA = tick0 + a.n_ticks;
     *d.tickB = tick0 + a.n_ticks - 1;
   }

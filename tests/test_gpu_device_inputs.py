@@ -14,6 +14,16 @@ from gym_traffic.core import TfxEngine  # noqa: E402
 from gym_traffic.devrng import PoissonMirror, gap_table, philox4x32  # noqa: E402
 
 
+@pytest.fixture(params=["resident", "pertick"], autouse=True)
+def step_path(request, monkeypatch):
+    """Both producers of the on-device inputs: inside the LDS-resident kernel k_res (Poisson stream and
+    greedy rule evaluated in the kernel, 2 envs per workgroup) and the per-tick kernels k_poisson /
+    k_greedy."""
+    monkeypatch.setenv("TFX_RESIDENT", "1" if request.param == "resident" else "0")
+    monkeypatch.setenv("TFX_RES_EPB", "2")
+    yield request.param
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     assert philox4x32(0, 0, 0, 0, 0, 0) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
@@ -86,3 +96,34 @@ def test_device_inputs_inside_the_agent_graph():
     assert int(eng.done_tick.max()) == 0
     assert torch.equal(eng.leading, ref.leading) and torch.equal(eng.lastcar, ref.lastcar)
     assert int(eng.cars_on_roads_flat().sum()) > 100
+
+
+def test_poisson_stream_continues_across_step_paths(monkeypatch):
+    """Calls shorter than TFX_RES_MIN_TICKS take the per-tick kernels (k_poisson), longer ones k_res: the
+    arrival stream's state (gap, car index) and the greedy controller's held action pass between them."""
+    monkeypatch.setenv("TFX_RESIDENT", "1")
+    monkeypatch.setenv("TFX_RES_MIN_TICKS", "4")
+    E, m, n, L, cap, cpt, spacing, seed = 3, 3, 2, 120.0, 16, 1.1, 4, 0xBEEF
+    eng = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    orc = OracleEnv(m, n, L, cap, eng.dest, eng.phases, eng.nexts, n_envs=E)
+    ph = np.zeros((E, eng.I), np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    eng.set_poisson(cpt, seed=seed)
+    eng.set_greedy(spacing)
+    mirror = PoissonMirror(cpt, seed, eng.n_entry, range(E))
+    act = np.zeros((E, eng.I), np.int32)
+    t = 0
+    for k in (1, 6, 2, 9, 3, 3, 11, 1, 5):
+        eng.step(k)
+        for _ in range(k):
+            if t % spacing == 0:
+                c = orc.cars_on_roads()
+                act = (c.reshape(E, eng.I, 4).dot([1, 1, -1, -1]) < 0).astype(np.int32)
+            cnt = mirror.next_tick()
+            orc.step(act, [[int(eng.entrypoints[j]) for j in range(eng.n_entry) for _ in range(cnt[q, j])] for q in range(E)])
+            t += 1
+        assert np.array_equal(eng.leading.cpu().numpy(), orc.leading), (k, t)
+        assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), (k, t)
+        assert np.array_equal(eng.obs.cpu().numpy(), orc.obs), (k, t)
+    assert eng.fused_ticks()[0] == 6 + 9 + 11 + 5 and int(eng.cars_on_roads_flat().sum()) > 20

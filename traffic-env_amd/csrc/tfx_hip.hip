@@ -346,7 +346,7 @@ bool res_try(tfx_handle h, int epb) {
   const Dev &d = h->d;
   const int threads = (LPR * epb * d.R + 63) / 64 * 64;
   if (threads > RES_MAX_THREADS) return false;
-  const size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, W);
+  const size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, d.n_entry, W);
   if (lds > (size_t)160 * 1024) return false;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<LPR, W>)),
@@ -393,10 +393,10 @@ int res_configure(tfx_handle h) {
   return TFX_OK;
 }
 
-// the resident kernel serves a call when the envs fit, trip times are not recorded (their order is the
-// serial loop's) and the arrivals do not come from the on-device Poisson stream (a per-tick producer)
+// the resident kernel serves a call when the envs fit and trip times are not recorded (their order is
+// the serial loop's)
 bool res_usable(tfx_handle h, int n_ticks) {
-  return h->res_epb > 0 && !h->poisson && !h->d.validate && n_ticks >= h->res_min_ticks;
+  return h->res_epb > 0 && !h->d.validate && n_ticks >= h->res_min_ticks;
 }
 
 int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi = 0, float *aobs = nullptr,
@@ -408,6 +408,8 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   a.aobs = aobs;
   a.areward = areward;
   a.adone = adone;
+  a.poisson = h->poisson ? 1 : 0;
+  a.ps = h->ps;
   a.epb = h->res_epb;
   a.n_ticks = n_ticks;
   a.greedy_spacing = h->greedy ? h->greedy_spacing : 0;

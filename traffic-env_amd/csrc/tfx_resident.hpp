@@ -31,6 +31,7 @@
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
 #include "tfx_move_t2.hpp"
+#include "tfx_misc.hpp"
 
 namespace tfx {
 
@@ -47,19 +48,23 @@ struct ResArgs {
   int tail, remi;
   float *aobs, *areward;  // [E][2r+I], [E][I] (may be null)
   uint8_t *adone;         // [E] (may be null)
+  // on-device Poisson arrivals (tfx_set_poisson): the stream of k_poisson, drawn inside the kernel
+  int poisson;
+  PoissonDev ps;
 };
 
 constexpr int RES_KH = 2;  // popped cars copied per handoff round
 constexpr int RES_MAX_THREADS = 512;  // lanes (= roads) per workgroup: 8 wavefronts, up to 256 VGPRs each
 
 // bytes of dynamic LDS for Tr road columns (Tr = lanes / lanes-per-road)
-__host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, bool W) {
+__host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, int n_entry, bool W) {
   const size_t ns = (size_t)(C - 1);
   size_t b = ns * Tr * sizeof(float2);
   if (W) b += ns * Tr * sizeof(float);
   b += (size_t)Tr * 8 * 4;               // ld, lc, kpop, cnt, tail, passed, ovf, ovfsp
   b += (size_t)epb * I * (2 * 8 + 4 + 4 + 4);  // light[2], rew, pdst, act
   b += (size_t)epb * 2 * 4 + 16;         // ovftick, fartick, maxpop[2]
+  b += (size_t)epb * (n_entry + 2) * 4;  // Poisson: this tick's cars per entry road, the stream's state
   return (b + 15) & ~(size_t)15;
 }
 
@@ -82,6 +87,9 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   int *s_ovftick = s_act + (size_t)epb * I;  // [epb] tick + 1 of the env's last overflow in this call
   int *s_fartick = s_ovftick + epb;          // [epb] tick + 1 of the last tick that needs the serial loop
   int *s_maxpop = s_fartick + epb;           // [2] most cars any road popped, by tick parity
+  int *s_spawn = s_maxpop + 4;               // [epb][n_entry] Poisson arrivals of the tick
+  int *s_gap = s_spawn + (size_t)epb * d.n_entry;  // [epb] whole ticks until the env's next car (-1: not drawn yet)
+  unsigned *s_draws = reinterpret_cast<unsigned *>(s_gap + epb);  // [epb] index of the env's next car
 
   const int h = LPR == 2 ? (int)(threadIdx.x & 1) : 0;  // which half of the road's cars this lane walks
   const bool hA = h == 0;                                // the road's first lane also does everything per road
@@ -148,6 +156,10 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     }
   }
   if (threadIdx.x == 0) s_maxpop[0] = s_maxpop[1] = 0;
+  if (a.poisson && (int)threadIdx.x < epb && (int)(blockIdx.x * epb + threadIdx.x) < d.E) {
+    s_gap[threadIdx.x] = a.ps.gap_left[blockIdx.x * epb + threadIdx.x];
+    s_draws[threadIdx.x] = a.ps.draws[blockIdx.x * epb + threadIdx.x];
+  }
   __syncthreads();
 
   int wait_acc = 0, det = 0;
@@ -164,6 +176,55 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     int kpop = 0, n_tot = 0, ovf_sp = 0;
     float tail_x = 0.0f;
     bool far = false;
+    if (a.poisson) {
+      // The reference's Poisson generator with the device RNG, exactly as k_poisson (tfx_misc.hpp) draws
+      // it: one wavefront per env evaluates 64 consecutive cars at a time; every car up to and
+      // including the first with a non-zero gap arrives in this tick.
+      const int lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+      for (int el = threadIdx.x >> 6; el < epb; el += n_waves) {
+        const int envp = blockIdx.x * epb + el;
+        int *hist = s_spawn + (size_t)el * d.n_entry;
+        for (int j = lane; j < d.n_entry; j += 64) hist[j] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (envp < d.E && !(d.agent_mode && s_ovftick[el] > tick0)) {
+          int gap = s_gap[el];
+          unsigned c0 = s_draws[el];
+          const unsigned gid = (unsigned)(envp + d.env_off);
+          unsigned u[4];
+          auto gap_of = [&](unsigned draw) {
+            philox4x32(draw, gid, 0x47415021u, 0u, a.ps.seed_lo, a.ps.seed_hi, u);
+            int k = 0;
+            while (k < a.ps.n_cdf - 1 && u[0] >= a.ps.cdf[k]) ++k;
+            return k;
+          };
+          if (gap < 0) gap = gap_of(0u);
+          if (gap > 0) {
+            --gap;
+          } else {
+            for (int guard = 0; guard < 1024; ++guard) {
+              const unsigned c = c0 + (unsigned)lane;
+              const int g = gap_of(2u + 2u * c);
+              const unsigned long long stop = __builtin_amdgcn_ballot_w64(g > 0);
+              const int f = stop ? __builtin_ctzll(stop) : 63;
+              if (lane <= f) {
+                philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, a.ps.seed_lo, a.ps.seed_hi, u);
+                atomicAdd(&hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
+              }
+              c0 += (unsigned)(f + 1);
+              if (stop) {
+                gap = __shfl(g, f, 64) - 1;
+                break;
+              }
+            }
+          }
+          if (lane == 0) {
+            s_gap[el] = gap;
+            s_draws[el] = c0;
+          }
+        }
+      }
+      __syncthreads();
+    }
     if (des && frozen) {
       s_light[(size_t)par * epb * I + li] = s_light[(size_t)(par ^ 1) * epb * I + li];
       // (the per-tick path's k_greedy keeps deciding for a stopped env, from its standing counts)
@@ -207,7 +268,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       tail_x = s_tail[t];
       if (ej >= 0) {
         const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-        const int c = spawn_count(d, env, e, ej, tick_sp, tt);
+        const int c = a.poisson ? s_spawn[(size_t)env_l * d.n_entry + ej] : spawn_count(d, env, e, ej, tick_sp, tt);
         for (int q = 0; q < c; ++q) {
           const int pos = wrap1(lc + 1, C);
           const float start = (lc != ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
@@ -580,6 +641,10 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       if (a.aobs)  // elapsed / 100 * (2 * phase - 1), computed in binary64 like the reference's NumPy expression
         a.aobs[(size_t)env * (2 * d.r + I) + 2 * d.r + isec] = (float)((double)pl.y / 100.0 * (double)(2 * pl.x - 1));
     }
+  }
+  if (a.poisson && (int)threadIdx.x < epb && (int)(blockIdx.x * epb + threadIdx.x) < d.E) {
+    a.ps.gap_left[blockIdx.x * epb + threadIdx.x] = s_gap[threadIdx.x];
+    a.ps.draws[blockIdx.x * epb + threadIdx.x] = s_draws[threadIdx.x];
   }
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if ((threadIdx.x & 63) == 0 && my_updates) veh_add(d.veh, my_updates);

@@ -136,7 +136,8 @@ def _uneven_worker(rank, world, port, out_dir):
         from gym_traffic.distributed import shard_range, RolloutGather
         lo, hi = shard_range(7, rank, world)                       # 4 + 3 envs
         n, L, I = hi - lo, 6, 2
-        g = RolloutGather(n, L, I, "cpu")
+        sizes = [b - a for a, b in (shard_range(7, r, world) for r in range(world))]
+        g = RolloutGather(n, L, I, "cpu", counts=sizes)
         ids = torch.arange(lo, hi, dtype=torch.int32)
         for step in range(5):                                      # starts never wait for the previous one
             g.start(ids[:, None].repeat(1, L) + 100 * step, (ids[:, None].repeat(1, I) + 0.25).float(),

@@ -127,3 +127,21 @@ def test_poisson_stream_continues_across_step_paths(monkeypatch):
         assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), (k, t)
         assert np.array_equal(eng.obs.cpu().numpy(), orc.obs), (k, t)
     assert eng.fused_ticks()[0] == 6 + 9 + 11 + 5 and int(eng.cars_on_roads_flat().sum()) > 20
+
+
+def test_vec_env_device_arrivals():
+    """TrafficVecEnv(spawn='device'): the on-device Poisson stream behind the batched surface - the
+    same trajectory as the engine driven directly, and sharding-independent through env_id_offset."""
+    from gym_traffic.envs.vec_env import TrafficVecEnv
+    venv = TrafficVecEnv(6, 3, 3, 150.0, capacity=20, spawn='device', local_cars_per_sec=0.2, seed=21)
+    ph = np.zeros((6, venv.engine.I), np.int32)
+    venv.reset(ph)
+    ref = TfxEngine(3, 3, 150.0, 20, n_envs=2, planes=2, env_id_offset=3)
+    ref.reset(ph[:2])
+    ref.set_poisson(venv.cars_per_sec * venv.rate, seed=21)
+    ref.set_actions(cycle_period=6)
+    for _ in range(4):
+        venv.agent_step(n_ticks=10, cycle_period=6)
+        ref.agent_step(10)
+    assert torch.equal(venv.engine.leading[3:5], ref.leading) and torch.equal(venv.engine.lastcar[3:5], ref.lastcar)
+    assert int(venv.cars_on_roads().sum()) > 30

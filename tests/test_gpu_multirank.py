@@ -40,7 +40,8 @@ def _rank(rank, world, port, out_dir):
         from gym_traffic.distributed import shard_range, RolloutGather
         lo, hi = shard_range(7, rank, world)                       # 4 + 3 envs
         eng = wl.setup_engine("cfg1", device="cuda:0", envs=hi - lo, env_id_offset=lo)
-        gather = RolloutGather(hi - lo, eng.obs_len, eng.I, eng.device)
+        sizes = [b - a for a, b in (shard_range(7, r, world) for r in range(world))]
+        gather = RolloutGather(hi - lo, eng.obs_len, eng.I, eng.device, counts=sizes)
         for _ in range(3):
             eng.step(10)
             gather.start(eng.obs, eng.rewards, eng.done)

@@ -26,7 +26,10 @@ class RolloutGather(object):
 
     DEPTH = 2
 
-    def __init__(self, n_local, obs_len, n_intersections, device, dst=0, group=None):
+    def __init__(self, n_local, obs_len, n_intersections, device, dst=0, group=None, counts=None):
+        """counts: envs per rank when the shards differ (`[hi - lo for lo, hi in (shard_range(total, r,
+        world) ...)]` - a pure function of the sharding, so no exchange is needed); default: every
+        rank holds n_local envs."""
         self.dst, self.group = dst, group
         on = dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -37,12 +40,9 @@ class RolloutGather(object):
         backend = dist.get_backend(group) if on else "none"
         self.stage_dev = torch.device("cpu") if (backend == "gloo" and self.device.type == "cuda") else self.device
         self.n, self.L, self.I = int(n_local), int(obs_len), int(n_intersections)
-        self.counts = [self.n]
-        if self.world > 1:
-            # shards may differ by one env: agree on the sizes once, on the host
-            sizes = [None] * self.world
-            dist.all_gather_object(sizes, self.n, group=group)
-            self.counts = [int(s) for s in sizes]
+        self.counts = [int(c) for c in counts] if counts is not None else [self.n] * self.world
+        if len(self.counts) != self.world or self.counts[self.rank] != self.n:
+            raise ValueError("counts must list every rank's envs, this rank's being n_local")
         self.n_max = max(self.counts)
         self.o_rew = self.n_max * self.L
         self.o_done = self.o_rew + self.n_max * self.I

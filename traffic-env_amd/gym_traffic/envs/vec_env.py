@@ -4,7 +4,9 @@ This is the batched form of the reference's TrafficEnv (traffic_env.py:221-394) 
 the same tick semantics per env, every env's arrays stacked along a leading dimension, no host
 round trip inside `step`.  Spawns come either from per-env replicas of the reference's seeded
 generators (`spawn='poisson'|'regular'`: host RandomState schedules, bit-identical per env to a
-reference env seeded `seed + env_id`) or from the on-device fixed-rate rule (`spawn='periodic'`).
+reference env seeded `seed + env_id`), from the on-device form of the reference's Poisson generator
+(`spawn='device'`: Philox streams keyed by (seed, global env id), no host work per tick - the one to
+use for throughput) or from the on-device fixed-rate rule (`spawn='periodic'`).
 Sharding across GPUs is by env id (gym_traffic/distributed.py); envs share nothing.
 """
 import numpy as np
@@ -38,12 +40,14 @@ class TrafficVecEnv(object):
             self._arrivals = ArrivalStreams([seed + self.env_id_offset + k for k in range(self.num_envs)],
                                             spawn == 'poisson', self.graph.entrypoints, eng.entry_index,
                                             max(1, eng.n_entry), self.cars_per_sec * self.rate)
+        elif spawn == 'device':
+            eng.set_poisson(self.cars_per_sec * self.rate, seed=seed)
         elif spawn == 'periodic':
             eng.set_spawns(period=spawn_period)
         elif spawn in (None, 'none'):
             eng.set_spawns()
         else:
-            raise ValueError("spawn must be poisson|regular|periodic|none")
+            raise ValueError("spawn must be poisson|regular|device|periodic|none")
         self._phase_rng = np.random.RandomState(seed + 7919 + self.env_id_offset)
         self.obs, self.rewards, self.done = eng.obs, eng.rewards, eng.done
 

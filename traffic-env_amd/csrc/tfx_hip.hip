@@ -274,7 +274,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   // and 8 rows in flight.  Measured k_move_t<8> vs <4, nt> per launch: cfg2 x 128 envs (143 MB of cars)
   // 0.0365 vs 0.0392 ms, x 256 0.048 vs 0.054, x 384 0.068 vs 0.080, x 512 (286 MB) 0.086 vs 0.093,
   // cfg4 x 16 (272 MB) 0.096 vs 0.103, x 24 (409 MB) 0.134 vs 0.150; at cfg2 x 1024 (573 MB) it is the
-  // other way round: 0.199 vs 0.173.
+  // other way round: 0.199 vs 0.173.  (12 or 16 rows in flight, or 8 resident blocks per CU: no better.)
   if (pvar == 0 && h->n_tpairs * sizeof(float2) <= (size_t)448 << 20) { h->step_kernel = "k_move_t"; return go(k_move_t<8>); }
   // beyond that every row is read once and written once per tick: non-temporal loads AND stores (0.82 -> 0.70 ms
   // at cfg2, and the following k_advance no longer waits for dirty lines: 0.057 -> 0.032 ms)

@@ -3,7 +3,6 @@ slice of the randomised differential test (tools/fuzz_vs_oracle.py) so that the 
 sampling new configurations.  Everything goes through the C ABI; the oracle is the checker."""
 import json
 import os
-import time
 
 import numpy as np
 import pytest
@@ -161,13 +160,15 @@ def test_transposed_handle_allocates_no_ring_copy_until_asked():
 
 
 def test_fuzz_slice_vs_oracle():
-    """~16 s of tools/fuzz_vs_oracle.py (two seeds derived from the date, so successive rounds sample
-    different cases): random shapes, layouts, pathological start states, validate mode."""
+    """~16 s of tools/fuzz_vs_oracle.py: random shapes, layouts, step paths, pathological start states,
+    validate mode.  Two fixed seeds per round (a gate should not roll new dice; the open-ended runs are
+    `python tools/fuzz_vs_oracle.py SEED`, round 2: seeds 31, 32, 41 = 6 300 cases clean, and
+    tools/fuzz_agent_step.py seeds 33, 42 = 25 700 cases) - the cases run are a prefix of the seed's
+    sequence, however fast the box is."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_vs_oracle as fz
-    day = int(time.strftime("%Y%m%d"))
     total = 0
-    for seed in (day, day + 1):
+    for seed in (20261004, 20261005):
         total += fz.run(seed, secs=8.0)
     assert total >= 4

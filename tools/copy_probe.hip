@@ -187,6 +187,99 @@ __global__ __launch_bounds__(256) void k_model_g(f2 *__restrict__ a, int *__rest
   }
 }
 
+// k_model_i: k_model's rolling stream on an INTERLEAVED layout - the rows k of the NT tiles of a
+// workgroup are contiguous (NT * 512 bytes), each wavefront still walks its own tile: do DRAM pages
+// like the longer contiguous runs?
+template <int U, int NT, bool RAGGED, bool WORDS, bool MATH>
+__global__ __launch_bounds__(256) void k_model_i(f2 *__restrict__ a, int *__restrict__ words, size_t n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const size_t n_groups = n_tiles / 4;
+  for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const size_t t = g * 4 + wv;
+    // group base: 4 tiles x 64 rows x 64 lanes; row k of sub-tile s at base + (k * NT + s') * 64 ...
+    f2 *col = (NT == 4) ? a + g * 4 * 4096 + (size_t)wv * 64 + lane
+                        : a + g * 4 * 4096 + (size_t)(wv >> 1) * 2 * 4096 + (size_t)(wv & 1) * 64 + lane;
+    const size_t rstride = (size_t)NT * 64;
+    unsigned h = (unsigned)(t * 64 + lane) * 2654435761u;
+    int n = RAGGED ? 40 + (int)((h >> 8) % 17u) : 48;
+    float acc = 0.f;
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+      int s0 = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s0 += w[q * n_tiles * 64];
+      n += (s0 & 0);
+      acc = (float)(s0 & 1);
+    }
+    int kmax = n;
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(kmax, off, 64);
+      kmax = o > kmax ? o : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    f2 pf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pf[u] = (u < n) ? __builtin_nontemporal_load(col + (size_t)u * rstride) : f2{0, 0};
+    float px = 1e9f, pv = 0.f;
+    for (int k0 = 0; k0 < kmax; k0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        if (k < kmax) {
+          f2 c = pf[u];
+          if (k + U < kmax) pf[u] = (k + U < n) ? __builtin_nontemporal_load(col + (size_t)(k + U) * rstride) : f2{0, 0};
+          if (k < n) {
+            f2 o = c;
+            if (MATH) {
+              float s = px - c.x - 4.f, q = c.y * 0.072f;
+              float st = 1.f + c.y * 2.f + c.y * (c.y - pv) * 0.1178f;
+              float r = st / (s + 1e-8f);
+              float dv = 3.f * (1.f - q * q * q * q - r * r);
+#pragma unroll
+              for (int z = 0; z < 12; ++z) dv = dv * 0.999f + 0.001f * r;
+              o.x = c.x + fmaxf(0.f, 0.5f * c.y + 0.125f * dv);
+              o.y = fmaxf(0.f, c.y + 0.5f * dv);
+              px = c.x;
+              pv = c.y;
+            } else {
+              o.x = c.x * 1.0001f + 0.5f;
+            }
+            __builtin_nontemporal_store(o, col + (size_t)k * rstride);
+            acc += o.x;
+          }
+        }
+      }
+    }
+    if (WORDS) {
+      int *w = words + (t * 64 + lane);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) w[(8 + q) * n_tiles * 64] = (int)acc + q;
+    }
+  }
+}
+
+#define MODELI(label, U, NT, RG, WD, MA, grid)                                                     \
+  do {                                                                                            \
+    const size_t n_tiles = bytes / 32768;                                                         \
+    hipEvent_t s, e;                                                                              \
+    hipEventCreate(&s);                                                                           \
+    hipEventCreate(&e);                                                                           \
+    for (int i = 0; i < 2; ++i)                                                                   \
+      hipLaunchKernelGGL((k_model_i<U, NT, RG, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(s);                                                                            \
+    for (int i = 0; i < 10; ++i)                                                                  \
+      hipLaunchKernelGGL((k_model_i<U, NT, RG, WD, MA>), dim3(grid), dim3(256), 0, 0, (f2 *)a, (int *)b, n_tiles); \
+    hipEventRecord(e);                                                                            \
+    hipEventSynchronize(e);                                                                       \
+    float ms = 0;                                                                                 \
+    hipEventElapsedTime(&ms, s, e);                                                               \
+    ms /= 10;                                                                                     \
+    printf("model %-38s grid %5d: %.3f ms\n", label, grid, ms);                                   \
+    hipEventDestroy(s);                                                                           \
+    hipEventDestroy(e);                                                                           \
+  } while (0)
+
 #define MODELG(label, G, RG, WD, MA, grid)                                                         \
   do {                                                                                            \
     const size_t n_tiles = bytes / 32768;                                                         \
@@ -288,6 +381,10 @@ int main(int argc, char **argv) {
     MODELG("grouped 16: ragged + words + arithmetic", 16, true, true, true, g);
     MODELG("grouped 8: ragged + words + arith, 4/CU", 8, true, true, true, cu * 4);
     MODELG("grouped 8: ragged + words + arith, 6/CU", 8, true, true, true, cu * 6);
+    MODELI("interleaved x4: 48 rows per road", 4, 4, false, false, false, g);
+    MODELI("interleaved x4: ragged + words + arith", 4, 4, true, true, true, g);
+    MODELI("interleaved x2: ragged + words + arith", 4, 2, true, true, true, g);
+    MODELI("interleaved x4, 8 rolling: ragged+w+a", 8, 4, true, true, true, g);
   }
   hipFree(a);
   hipFree(b);

@@ -269,9 +269,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    run(a.warmup)
-    eng.reset_counters()
+    # (the HIP events of the per-kernel timing are created BEFORE the warm-up and re-armed after it, so that
+    # no host work sits between the warm-up and the timed region: after even a millisecond of idleness
+    # the first launch runs at a lower clock, which a 2 ms k_res launch - cfg0 / cfg1 - would show in full)
     eng.profile(a.steps)
+    run(a.warmup)
+    eng.profile_read()
+    eng.reset_counters()
     fence()
     t0 = time.perf_counter()
     run(a.steps)

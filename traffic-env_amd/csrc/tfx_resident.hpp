@@ -94,8 +94,15 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   const int h = LPR == 2 ? (int)(threadIdx.x & 1) : 0;  // which half of the road's cars this lane walks
   const bool hA = h == 0;                                // the road's first lane also does everything per road
   const int t = LPR == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x;  // the road's column
-  const int env_l = t / R, e = t - env_l * R;
+  // Columns follow the storage-slot order of the env's roads (interior train roads, entry roads, exit
+  // roads: build_slots) rather than road ids: roads of a kind have similar car counts, a wavefront
+  // walks as far as its longest road, and a wavefront of short roads frees its SIMD early for the
+  // other workgroups of the CU.
+  const int env_l = t / R, rc = t - env_l * R;  // the road's column within its env
+  const int cbase = t - rc;                      // column of the env's first road slot
   const int env = blockIdx.x * epb + env_l;
+  const int e = (env_l < epb && env < d.E) ? d.slot_road[rc] : 0;
+  auto COL = [&](int road) { return cbase + d.road_slot[road]; };
   const bool valid = env_l < epb && env < d.E;
   const int id = valid ? env * R + e : 0;
   const int tick0 = *d.tickA;  // advanced by k_tick_add after this kernel, never inside it
@@ -107,7 +114,9 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   const int ej = valid ? d.entry_idx[e] : -1;
   const int pe = valid ? d.pred[e] : -1;
   const int nx = train ? d.nexts[e] : -1;
-  const int tn = t - e + nx, tp = t - e + pe;  // lanes of the next / previous road
+  const int tn = nx >= 0 ? COL(nx) : 0, tp = pe >= 0 ? COL(pe) : 0;  // columns of the next / previous road
+  // columns of the four roads into intersection `isec` (greedy rule, rewards, remi)
+  const int c4[4] = {train ? COL(isec) : 0, train ? COL(I + isec) : 0, train ? COL(2 * I + isec) : 0, train ? COL(3 * I + isec) : 0};
   const bool des = train && dir == 0 && hA;    // this lane also keeps intersection `isec`
   auto RG = [&](int slot, int lane) -> float2 & { return ring[(size_t)(slot - 1) * T + lane]; };
   auto RW = [&](int slot, int lane) -> float & { return ringw[(size_t)(slot - 1) * T + lane]; };
@@ -229,8 +238,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       s_light[(size_t)par * epb * I + li] = s_light[(size_t)(par ^ 1) * epb * I + li];
       // (the per-tick path's k_greedy keeps deciding for a stopped env, from its standing counts)
       if (a.greedy_spacing > 0 && tick % a.greedy_spacing == 0) {
-        const int b = t - e + isec;
-        s_act[li] = (s_cnt[b] + s_cnt[b + I] - s_cnt[b + 2 * I] - s_cnt[b + 3 * I] < 0) ? 1 : 0;
+        s_act[li] = (s_cnt[c4[0]] + s_cnt[c4[1]] - s_cnt[c4[2]] - s_cnt[c4[3]] < 0) ? 1 : 0;
       }
     }
     if (run && hA) {
@@ -249,8 +257,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
           // two E-W ones (cars_on_roads().dot([1,1,-1,-1]) < 0); held in between
           int act = s_act[li];
           if (tick % a.greedy_spacing == 0) {
-            const int b = t - e + isec;
-            act = (s_cnt[b] + s_cnt[b + I] - s_cnt[b + 2 * I] - s_cnt[b + 3 * I] < 0) ? 1 : 0;
+            act = (s_cnt[c4[0]] + s_cnt[c4[1]] - s_cnt[c4[2]] - s_cnt[c4[3]] < 0) ? 1 : 0;
           }
           int change;
           if (d.learn_switch) { change = act != 0; ph_new = ((pl.x != 0) != (act != 0)) ? 1 : 0; }
@@ -448,22 +455,22 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     int ovf = 0;
     if (serial_env && e == 0 && run && hA) {
       // literal single-lane loop for this env (a handed-off car is itself beyond the next road's end)
-      const int b = t;  // lane of road 0
+      // (q runs over ROAD IDS in the reference's order; COL(q) is where road q lives)
       float *rew = s_rew + (size_t)env_l * I;
       int overflowed = 0;
       if (!(d.accum_rewards && tt > 0))
         for (int i = 0; i < I; ++i) rew[i] = 0.0f;
       for (int q = 0; q < R; ++q) {  // spawn overflows happened before move_cars
-        const int sp = s_ovfsp[b + q];
+        const int sp = s_ovfsp[COL(q)];
         if (sp > 0) {
           overflowed = 1;
           if (q < d.r)
             for (int j = 0; j < sp; ++j) rew[q % I] -= d.ovf_pen;
         }
       }
-      for (int q = 0; q < d.r; ++q) s_passed[b + q] -= s_kpop[b + q];  // the parallel form's counts: recounted below
+      for (int q = 0; q < d.r; ++q) s_passed[COL(q)] -= s_kpop[COL(q)];  // the parallel form's counts: recounted below
       for (int q = 0; q < R; ++q) {
-        const int tq = b + q;
+        const int tq = COL(q);
         int l = s_ld[tq];
         while (l != s_lc[tq] && RG(wrap1(l + 1, C), tq).x > d.length) {
           const int newlead = wrap1(l + 1, C);
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
             s_passed[tq] += 1;
             s_pdst[env_l * I + q % I] = 1;
             const float xc = RG(newlead, tq).x - d.length;
-            const int tr = b + nr;
+            const int tr = COL(nr);
             const int lcn = s_lc[tr], ldn = s_ld[tr];
             const int pos = wrap1(lcn + 1, C);
             const float start = (lcn != ldn) ? (RG(lcn, tr).x - d.car_l) - d.car_s0 : INFINITY;
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
         }
       }
       for (int q = 0; q < R; ++q) {
-        const int tq = b + q;
+        const int tq = COL(q);
         const int n = ring_count(s_ld[tq], s_lc[tq], C);
         s_cnt[tq] = n;
         s_tail[tq] = (n > 0) ? RG(s_lc[tq], tq).x : 0.0f;
@@ -548,8 +555,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     }
     // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
     if (des && run && !serial_env) {
-      const int b = t;  // lane of road `isec` (dir 0)
-      const int sum = s_ovf[b] + s_ovf[b + I] + s_ovf[b + 2 * I] + s_ovf[b + 3 * I];
+      const int sum = s_ovf[c4[0]] + s_ovf[c4[1]] + s_ovf[c4[2]] + s_ovf[c4[3]];
       float rw = (d.accum_rewards && tt > 0) ? s_rew[li] : 0.0f;
       for (int j = 0; j < sum; ++j) rw -= d.ovf_pen;
       s_rew[li] = rw;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const bool green = ((q < 2) ? 1 : 0) != pl.x;
-          const bool waiting = s_ovf[t + q * I] > 0;
+          const bool waiting = s_ovf[c4[q]] > 0;
           if (waiting && !green && !pd) rw -= 0.5f;
           else if (pd && green && !waiting) rw += 0.5f;
         }

@@ -346,8 +346,21 @@ bool res_try(tfx_handle h, int epb) {
   const Dev &d = h->d;
   const int threads = (LPR * epb * d.R + 63) / 64 * 64;
   if (threads > RES_MAX_THREADS) return false;
-  const size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, d.n_entry, W);
+  size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, d.n_entry, W);
   if (lds > (size_t)160 * 1024) return false;
+  {
+    // Even placement: when every workgroup of the launch is resident at once the dispatcher may stack
+    // seven of them on some CUs and one on others (measured: the same cfg1 x 1024 launch takes 10 or
+    // 14.5 us per tick from run to run).  Asking for 1/b of a CU's LDS, b = workgroups per CU the launch
+    // needs, leaves the dispatcher no such choice.
+    const long grid = ((long)d.E + epb - 1) / epb;
+    long per_cu = (grid + h->n_cu - 1) / h->n_cu;
+    const long cap = (long)((size_t)160 * 1024 / lds);
+    if (per_cu > cap) per_cu = cap;
+    if (per_cu < 1) per_cu = 1;
+    const size_t padded = ((size_t)160 * 1024 / (size_t)per_cu) & ~(size_t)255;
+    if (!getenv("TFX_RES_NOPAD") && padded > lds) lds = padded;
+  }
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<LPR, W>)),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

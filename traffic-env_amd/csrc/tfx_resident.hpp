@@ -171,6 +171,20 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   }
   __syncthreads();
 
+  // The on-device rules divide by run-time periods: ((tick + env % P) / P) & 1, tick % P, e % P.  The
+  // quotients and remainders are carried from tick to tick instead (a division is ~40 instructions).
+  const int cyc_P = d.action_period > 0 ? d.action_period : 1;
+  int cyc_rem = 0, cyc_q = 0;
+  if (d.action_mode == TFX_ACTION_CYCLE && a.greedy_spacing <= 0) {
+    const int s0 = tick0 + (env + d.env_off) % cyc_P;
+    cyc_q = s0 / cyc_P;
+    cyc_rem = s0 - cyc_q * cyc_P;
+  }
+  const int sp_P = d.spawn_period > 0 ? d.spawn_period : 1;
+  const int sp_phase = e % sp_P;  // entry road e gets a car when tick % P == e % P
+  int sp_rem = tick0 % sp_P;
+  const int gr_P = a.greedy_spacing > 0 ? a.greedy_spacing : 1;
+  int gr_rem = tick0 % gr_P;
   int wait_acc = 0, det = 0;
   bool det_set = false;
   float xL = INFINITY;
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
 
   for (int tt = 0; tt < a.n_ticks; ++tt) {
     const int tick = tick0 + tt, par = tt & 1;
+    const bool gr_now = gr_rem == 0;  // a tick in which the greedy controller decides
     // env stopped for the rest of the agent step (`if done: break`): it overflowed earlier in this call
     const bool frozen = d.agent_mode && valid && s_ovftick[env_l] > tick0;
     const bool run = valid && !frozen;
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     if (des && frozen) {
       s_light[(size_t)par * epb * I + li] = s_light[(size_t)(par ^ 1) * epb * I + li];
       // (the per-tick path's k_greedy keeps deciding for a stopped env, from its standing counts)
-      if (a.greedy_spacing > 0 && tick % a.greedy_spacing == 0) {
+      if (a.greedy_spacing > 0 && gr_now) {
         s_act[li] = (s_cnt[c4[0]] + s_cnt[c4[1]] - s_cnt[c4[2]] - s_cnt[c4[3]] < 0) ? 1 : 0;
       }
     }
@@ -256,14 +271,20 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
           // greedy: every `spacing` ticks phase 1 iff the two N-S approaches hold more cars than the
           // two E-W ones (cars_on_roads().dot([1,1,-1,-1]) < 0); held in between
           int act = s_act[li];
-          if (tick % a.greedy_spacing == 0) {
+          if (gr_now) {
             act = (s_cnt[c4[0]] + s_cnt[c4[1]] - s_cnt[c4[2]] - s_cnt[c4[3]] < 0) ? 1 : 0;
           }
           int change;
           if (d.learn_switch) { change = act != 0; ph_new = ((pl.x != 0) != (act != 0)) ? 1 : 0; }
           else { change = (pl.x != 0) != (act != 0); ph_new = act; }
           el_new = change ? 0 : pl.y + 1;
-          if (des && tick % a.greedy_spacing == 0) s_act[li] = act;  // (read by the others in later ticks only)
+          if (des && gr_now) s_act[li] = act;  // (read by the others in later ticks only)
+        } else if (d.action_mode == TFX_ACTION_CYCLE) {  // light_next with the carried quotient
+          const int act = cyc_q & 1;
+          int change;
+          if (d.learn_switch) { change = act != 0; ph_new = ((pl.x != 0) != (act != 0)) ? 1 : 0; }
+          else { change = (pl.x != 0) != (act != 0); ph_new = act; }
+          el_new = change ? 0 : pl.y + 1;
         } else {
           light_next(d, env, isec, tick, tt, pl.x, pl.y, ph_new, el_new);
         }
@@ -274,8 +295,8 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       // ---- spawns (add_new_cars :274-283 -> add_car :97-114): straight into the ring -------------
       tail_x = s_tail[t];
       if (ej >= 0) {
-        const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-        const int c = a.poisson ? s_spawn[(size_t)env_l * d.n_entry + ej] : spawn_count(d, env, e, ej, tick_sp, tt);
+        const int c = a.poisson ? s_spawn[(size_t)env_l * d.n_entry + ej]
+                      : (d.spawn_mode == TFX_SPAWN_PERIODIC ? (sp_rem == sp_phase ? 1 : 0) : spawn_count(d, env, e, ej, 0, tt));
         for (int q = 0; q < c; ++q) {
           const int pos = wrap1(lc + 1, C);
           const float start = (lc != ld) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
@@ -305,13 +326,6 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
       const int n_first = LPR == 2 ? (n_tot + 1) >> 1 : n_tot;
       const int my_k0 = hA ? 0 : n_first;
       const int my_n = run ? (hA ? n_first : n_tot - n_first) : 0;
-      int kmax = my_n;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(kmax, off, 64);
-        kmax = o > kmax ? o : kmax;
-      }
-      kmax = __builtin_amdgcn_readfirstlane(kmax);
       float xprev = xL, vprev = 0.0f, llv = 0.0f;
       const int head = wrap1(ld + 1, C);
       if (LPR == 2 && !hA && my_n > 0) {
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
         pf[u] = (u < my_n) ? RG(slot, t) : make_float2(0.0f, 0.0f);
         slot = wrap1(slot + 1, C);
       }
-      for (int k0 = 0; k0 < kmax; k0 += G) {
+      for (int k0 = 0; __builtin_amdgcn_ballot_w64(k0 < my_n) != 0ull; k0 += G) {  // while any lane has cars left
         float2 cur[G];
         int csl[G];
 #pragma unroll
@@ -351,13 +365,11 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
           cur[u] = pf[u];
           csl[u] = psl[u];
         }
-        if (k0 + G < kmax) {
 #pragma unroll
-          for (int u = 0; u < G; ++u) {
-            psl[u] = slot;
-            pf[u] = (k0 + G + u < my_n) ? RG(slot, t) : make_float2(0.0f, 0.0f);
-            slot = wrap1(slot + 1, C);
-          }
+        for (int u = 0; u < G; ++u) {  // the next group's cars (per-lane guards: nothing is read past a lane's share)
+          psl[u] = slot;
+          pf[u] = (k0 + G + u < my_n) ? RG(slot, t) : make_float2(0.0f, 0.0f);
+          slot = wrap1(slot + 1, C);
         }
         float xl[G], vl[G], ll[G], bden[G];
         xl[0] = xprev;
@@ -563,6 +575,9 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
     if (valid && e == 0 && hA && run && !serial_env && s_ovftick[env_l] == tick + 1) d.done_tick[env] = tick + 1;
     // (no barrier here: what the next tick reads before its first barrier - s_cnt / s_tail of the next
     // road, the light words of the other parity, the overflow stamps - was written before B3)
+    if (++cyc_rem == cyc_P) { cyc_rem = 0; ++cyc_q; }
+    if (++sp_rem == sp_P) sp_rem = 0;
+    if (++gr_rem == gr_P) gr_rem = 0;
   }
   __syncthreads();
 

@@ -162,8 +162,8 @@ def test_transposed_handle_allocates_no_ring_copy_until_asked():
 def test_fuzz_slice_vs_oracle():
     """~16 s of tools/fuzz_vs_oracle.py: random shapes, layouts, step paths, pathological start states,
     validate mode.  Two fixed seeds per round (a gate should not roll new dice; the open-ended runs are
-    `python tools/fuzz_vs_oracle.py SEED`, round 2: seeds 31, 32, 41 = 6 300 cases clean, and
-    tools/fuzz_agent_step.py seeds 33, 42 = 25 700 cases) - the cases run are a prefix of the seed's
+    `python tools/fuzz_vs_oracle.py SEED`, round 2: seeds 31, 32, 41, 51 = 12 000 cases clean, and
+    tools/fuzz_agent_step.py seeds 33, 42, 52 = 44 500 cases) - the cases run are a prefix of the seed's
     sequence, however fast the box is."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))

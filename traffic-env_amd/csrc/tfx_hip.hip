@@ -1,9 +1,14 @@
 // tfx_hip.hip - MI355X (gfx950 / CDNA4) implementation of the IDM traffic-env tick behind the
 // C ABI of include/tfx.h.  Written for wave64; no other target is supported.
 //
-// One tick (reference: gym_traffic/envs/traffic_env.py:224-248, TrafficEnv._step) is two kernels:
-//   k_move_dma / k_move<WPR>  (tfx_move_dma.hpp, tfx_move_generic.hpp)  lights, spawns, IDM, counts
-//   k_advance                 (tfx_advance.hpp)                         ring pop + handoff, rewards
+// One tick (reference: gym_traffic/envs/traffic_env.py:224-248, TrafficEnv._step) is
+//   * for envs that fit a compute unit's LDS: part of ONE launch per tfx_step / tfx_agent_step call -
+//     k_res (tfx_resident.hpp), the cars resident on chip for all the ticks of the call;
+//   * otherwise two kernels:
+//       k_move_t / k_move_ts (transposed layout: tfx_move_t.hpp, tfx_move_ts.hpp; A/B: tfx_move_t2.hpp)
+//       or k_move_dma / k_move<WPR> (ring layout: tfx_move_dma.hpp, tfx_move_generic.hpp)
+//                                                          lights, spawns, IDM, counts, compaction
+//       k_advance (tfx_advance.hpp, tfx_advance_t.hpp)     ring pop + handoff, rewards, light words
 // plus the cold kernels of tfx_misc.hpp.  This file is the host side: tables, scratch, launches.
 #include <hip/hip_runtime.h>
 

@@ -5,8 +5,8 @@ render/_render, cars_on_roads, remi_reward` and the attributes agents and wrappe
 rewards, passed, detected, current_phase, elapsed, waiting, passed_dst, leading, lastcar, state,
 trip_times, steps, generated_cars, graph, action_space, observation_space, reward_size`).  NumPy in,
 NumPy out, one env - exactly what algorithms/*.py and traffic_test.py's wrappers expect.  All
-simulation state lives in device tensors owned by a TfxEngine (gym_traffic/core.py); every tick is
-two HIP kernels.  There is no CPU step path.
+simulation state lives in device tensors owned by a TfxEngine (gym_traffic/core.py); a tick is one
+HIP kernel launch (grids that fit a compute unit's LDS) or two.  There is no CPU step path.
 
 Differences from the reference that a caller can observe:
   * `CAPACITY` is a constructor/`set_graph` parameter (module default 20) instead of a frozen

@@ -210,11 +210,14 @@ int tfx_fastdiv_status(tfx_handle h, int32_t *enabled, uint64_t *mismatches);
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road);
 /* Ticks of this handle that ran in the LDS-resident multi-tick kernel (k_res: every tick of a tfx_step
  * or tfx_agent_step call in ONE launch, the envs' cars held in a compute unit's LDS) since tfx_create,
- * and whether the handle's envs fit it at all (`capable`: one lane per road, at most 512 lanes and
- * 160 KB of rings per workgroup - cfg0, cfg1, the reference's 3x3 default do; cfg2 and cfg4 do not).
- * A capable handle takes k_res on its own unless trip times are recorded (validate mode) or the
- * arrivals come from the on-device Poisson stream; results are bit-identical either way.
- * TFX_RESIDENT=0 in the environment (read by tfx_bind_buffers) turns it off. */
+ * and whether the handle's envs fit it at all (`capable`: two lanes per road - or one - within 512
+ * lanes and 160 KB of rings per workgroup: cfg0, cfg1, the reference's 3x3 default do; cfg2 and cfg4
+ * do not).  A capable handle takes k_res on its own unless trip times are recorded (validate mode);
+ * every input rule runs inside it (held / per-tick buffers, fixed cycle, periodic arrivals, the
+ * on-device Poisson stream, the greedy controller) and tfx_agent_step's remi / observation / done tail
+ * too; results are bit-identical either way.  Environment switches read by tfx_bind_buffers:
+ * TFX_RESIDENT=0 turns it off, TFX_RES_LPR=1 forces one lane per road, TFX_RES_EPB=n packs n envs per
+ * workgroup, TFX_RES_MIN_TICKS=n leaves calls shorter than n ticks to the per-tick kernels. */
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
 /* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
  * "k_move_dma", ...), for the roofline report; "" before the first step */

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResA
   auto COL = [&](int road) { return cbase + d.road_slot[road]; };
   const bool valid = env_l < epb && env < d.E;
   const int id = valid ? env * R + e : 0;
-  const int tick0 = *d.tickA;  // advanced by k_tick_add after this kernel, never inside it
+  const int tick0 = *d.tickA;  // advanced by k_tick_add after this kernel (inside it only when it is one workgroup)
   const bool train = valid && e < d.r;
   const int dir = train ? e / I : 0;
   const int isec = train ? e - dir * I : 0;

@@ -26,15 +26,14 @@ TFX_MOVE_VARIANT=104 prof cfg2_t2_sq --kernel-trace --pmc $SQ -- --config cfg2
 TFX_MOVE_VARIANT=104 prof cfg2_t2_kt --kernel-trace --stats -- --config cfg2
 TFX_RESIDENT=0 prof cfg1_pertick_kt --kernel-trace --stats -- --config cfg1
 cd $R
-# (cfg0 / cfg1: a k_res launch of 200 ticks lasts 1-3 ms and the first launches after idle run at a
-# lower clock - 15 us per tick against 10 in the steady state - so these two get a long warm-up)
+# (cfg0 / cfg1: k_res runs the whole timed region as ONE launch of 2 ms per 200 ticks: timed over 2000)
 for cfg in cfg2 cfg1 cfg0 cfg4; do
-  WU=20; case $cfg in cfg0|cfg1) WU=600;; esac
-  python3 bench.py --config $cfg --steps 200 --warmup $WU $( [ $cfg = cfg2 ] || echo --no-cpu-baseline ) > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+  WU=20; ST=200; case $cfg in cfg0|cfg1) WU=600; ST=2000;; esac
+  python3 bench.py --config $cfg --steps $ST --warmup $WU $( [ $cfg = cfg2 ] || echo --no-cpu-baseline ) > $O/bench_$cfg.json 2> $O/bench_$cfg.err
   echo "bench $cfg: $(python3 -c "import json;d=json.load(open('$O/bench_$cfg.json'));print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])")"
 done
 TFX_RESIDENT=0 python3 bench.py --config cfg1 --steps 200 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_pertick.json 2>/dev/null
-python3 bench.py --config cfg1 --envs 4096 --steps 200 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_4096.json 2>/dev/null
+python3 bench.py --config cfg1 --envs 4096 --steps 1000 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_4096.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 256 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_256.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg2_32768.json 2>/dev/null
 ( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt

@@ -68,8 +68,15 @@ __host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, i
   return (b + 15) & ~(size_t)15;
 }
 
+// At most 128 VGPRs (4 wavefronts per SIMD; the compiler spills ~10 registers to do it): with the 140 it
+// would take the kernel fits exactly 3 wavefronts per SIMD, i.e. exactly the 12 wavefronts of the four
+// 3-wavefront workgroups a CU gets at cfg1 x 1024 - but only if the dispatcher spreads them 3-3-3-3 over the
+// SIMDs.  After idleness or a different kernel it did not: a CU then held three workgroups, the fourth ran
+// in a second round and the whole launch took 1.45x (rocprofv3: same clock, same wave-cycles; 12 launches of
+// 36 in a loop that interleaves another kernel, 0 of 36 with this bound, and the steady state is no slower).
 template <int LPR, bool W>
-__global__ __launch_bounds__(RES_MAX_THREADS) void k_res(const Dev d, const ResArgs a) {
+__global__ __launch_bounds__(RES_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void k_res(const Dev d, const ResArgs a) {
   static_assert(LPR == 1 || LPR == 2, "one or two lanes per road");
   extern __shared__ __align__(16) unsigned char res_smem[];
   const int T = blockDim.x / LPR, C = d.C, NS = C - 1, R = d.R, I = d.I;  // T: road columns of the workgroup

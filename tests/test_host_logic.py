@@ -250,3 +250,32 @@ def test_arrival_streams_threads_do_not_change_the_streams(monkeypatch):
     cb, mb = b.next_ticks(64)
     assert np.array_equal(ca, cb) and np.array_equal(ma, mb) and int(ma.sum()) > 10000
     assert a.random_state(699).get_state()[2] == b.random_state(699).get_state()[2]
+
+
+def test_pmc_traffic_is_reported_only_for_the_profiled_sources(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 summary; it must vanish (null) as soon
+    as the kernel sources differ from the ones that were profiled, or the kernel / workload is another."""
+    import json
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import bench
+    import pmc_summary
+    h = pmc_summary.csrc_hash()
+    assert len(h) == 16 and h == pmc_summary.csrc_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    good = {"kernel": "k_move_t", "csrc_hash": h, "hbm_bytes_per_tick": 123.0}
+    (prof / "pmc_cfgX.json").write_text(json.dumps(good))
+    (prof / "pmc_cfgY.json").write_text(json.dumps(dict(good, csrc_hash="0" * 16)))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.load_pmc_traffic("cfgX", "k_move_t") == 123.0
+    assert bench.load_pmc_traffic("cfgX", "k_res") is None          # another kernel moved the cars
+    assert bench.load_pmc_traffic("cfgY", "k_move_t") is None       # profiled on other sources
+    assert bench.load_pmc_traffic("cfgZ", "k_move_t") is None       # never profiled
+    # the committed summaries carry a hash and name their kernel
+    for cfg in ("cfg1", "cfg2", "cfg4"):
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg)))
+        assert len(d["csrc_hash"]) == 16 and d["kernel"] in pmc_summary.MOVERS and d["hbm_bytes_per_tick"] > 0

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 8
+#define TFX_ABI_VERSION 9
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -219,6 +219,12 @@ int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_
  * TFX_RESIDENT=0 turns it off, TFX_RES_LPR=1 forces one lane per road, TFX_RES_EPB=n packs n envs per
  * workgroup, TFX_RES_MIN_TICKS=n leaves calls shorter than n ticks to the per-tick kernels. */
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
+/* Ticks of this handle that ran as two-tick passes since tfx_create (transposed layout: k_move_tt takes every
+ * car but the head of each road through TWO ticks per trip through HBM, k_edge finishes the second tick for
+ * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp).  tfx_step uses them on its own
+ * for calls of three ticks or more whose launches fill the chip, outside validate mode; results are
+ * bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0 turns them off, TFX_PAIRS=2 forces them at any size. */
+int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
 /* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
  * "k_move_dma", ...), for the roofline report; "" before the first step */
 const char *tfx_step_kernel(tfx_handle h);

@@ -1,0 +1,147 @@
+"""Two ticks per pass over the cars (csrc/tfx_move_tt.hpp): k_move_tt takes every car but the head of its
+road through two ticks in one trip through HBM, k_edge finishes the second tick for the heads and for the
+cars that joined a road in between.  tfx_step uses the pairs on its own for big launches; here they are
+forced at test sizes (TFX_PAIRS=2) and must be bit-identical to the tick-by-tick kernels and to the oracle:
+pathological ring states (wrapped, full, empty, unsorted, cars several road lengths past the end so that
+handed-off cars cascade, more than two pops per road and tick), per-tick action and spawn buffers, the
+on-device rules, every capacity class, odd and even call lengths."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import (assert_engines_equal, assert_same_state, counts, load_both, oracle_like,
+                             random_state)
+from test_gpu_fused import engine_with
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from gym_traffic import workload as wl  # noqa: E402
+
+
+def pairs_engine(E, **cfg):
+    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2"}, E, **cfg)
+    assert eng.pair_ticks() == 0
+    return eng
+
+
+def pertick_engine(E, **cfg):
+    return engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "0"}, E, **cfg)
+
+
+def paired(T):
+    """ticks of a T-tick call that run as pairs: all but the last one or two"""
+    return 2 * ((T - 1) // 2) if T >= 3 else 0
+
+
+@pytest.mark.parametrize("m,n,C,length", [(2, 2, 10, 60.0), (3, 2, 20, 120.0), (4, 4, 34, 200.0),
+                                          (2, 3, 66, 400.0), (5, 3, 12, 80.0), (1, 1, 6, 50.0),
+                                          (2, 2, 130, 800.0)])
+@pytest.mark.parametrize("sorted_x", [True, False])
+def test_pairs_random_states_vs_oracle(m, n, C, length, sorted_x):
+    rng = np.random.RandomState(8642 + C + int(sorted_x))
+    E = 5
+    eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    orc = oracle_like(eng)
+    ran = 0
+    for trial, T in enumerate([3, 4, 7, 8, 5, 11]):
+        x, v, w, leading, lastcar = random_state(rng, E, eng.R, C, length, crowd=rng.choice([0.3, 0.8]),
+                                                 beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=sorted_x)
+        if trial >= 4:
+            # leave the fast-division domain: enormous and denormal speeds, exact-zero gap denominators
+            v[rng.rand(*v.shape) < 0.02] = 3e7
+            v[rng.rand(*v.shape) < 0.02] = 1e-30
+            pick = rng.rand(*x[:, :, 2:].shape) < 0.05
+            x[:, :, 2:][pick] = (x[:, :, 1:-1] - np.float32(4.0))[pick]
+            np.put_along_axis(x, leading[:, :, None].astype(np.int64), np.inf, axis=2)
+        phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        elapsed = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
+        load_both(eng, orc, x, v, w, leading, lastcar, phase, elapsed)
+        eng.set_tick(60)
+        orc.steps[:] = 60
+        acts = rng.randint(2, size=(T, E, eng.I)).astype(np.int32)
+        roads = [[rng.choice(eng.entrypoints, size=rng.randint(0, 4)).tolist() for _ in range(E)]
+                 for _ in range(T)]
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+        eng.step(T)
+        ran += paired(T)
+        done = np.zeros(E, bool)
+        for t in range(T):
+            done |= orc.step(acts[t], roads[t])[2].astype(bool)
+        assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), trial
+        assert_same_state(eng, orc, "trial %d (%d ticks)" % (trial, T))
+    assert eng.pair_ticks() == ran and eng.step_kernel() == "k_move_tt"
+
+
+@pytest.mark.parametrize("chunk", [3, 10, 25])
+def test_pairs_equal_tick_by_tick_on_device_rules(chunk):
+    """The bench's inputs (fixed-cycle lights, periodic arrivals), dense enough that rings overflow: 60 ticks in
+    calls of `chunk` ticks == the same with the pairs disabled; counters and done flags included."""
+    E, T = 9, 60
+    cfg = dict(m=4, n=4, length=200.0, capacity=34, rate=0.5)
+    a = pairs_engine(E, **cfg)
+    c = pertick_engine(E, **cfg)
+    x, v, leading, lastcar = wl.prefill_one_env(4, 4, 200.0, 34, 24, 8.0)
+    for eng in (a, c):
+        eng.reset(np.zeros((E, eng.I), np.int32))
+        eng.load_state(np.repeat(x[None], E, 0), np.repeat(v[None], E, 0), np.repeat(leading[None], E, 0),
+                       np.repeat(lastcar[None], E, 0))
+        eng.set_spawns(period=3)
+        eng.set_actions(cycle_period=7)
+        eng.reset_counters()
+    done = 0
+    while done < T:
+        a.step(min(chunk, T - done))
+        done += min(chunk, T - done)
+    c.step(T)
+    assert a.pair_ticks() > 0 and c.pair_ticks() == 0
+    assert_engines_equal(a, c)
+    assert a.vehicle_updates() == c.vehicle_updates() > 0
+    assert a.tick == c.tick == T
+    assert torch.equal(a.done_tick, c.done_tick) and int(a.done_tick.max()) > 0
+
+
+def test_pairs_golden_ints(golden_cache):
+    """A captured reference run fed through per-tick buffers in uneven chunks: the integers equal the
+    reference's for the first 120 ticks, everything equals the oracle."""
+    g = golden_cache("g3x3_default")
+    sc = g.sc
+    eng = pairs_engine(1, m=sc["m"], n=sc["n"], length=sc["L"], capacity=sc["C"], rate=sc["rate"])
+    orc = oracle_like(eng)
+    eng.reset(g["init_phase"])
+    orc.reset(g["init_phase"])
+    t = 0
+    for chunk in [3, 4, 5, 13, 10, 10, 7, 25, 3, 8, 32]:
+        acts = g["actions"][t:t + chunk][:, None, :]
+        sp = np.stack([counts(eng, [g.spawns(t + j)]) for j in range(chunk)])
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=sp, per_tick=True)
+        eng.step(chunk)
+        for j in range(chunk):
+            orc.step(g["actions"][t + j], [g.spawns(t + j)])
+        t += chunk
+        assert_same_state(eng, orc, "tick %d" % t)
+        assert np.array_equal(eng.leading[0].cpu().numpy(), g["leading"][t])
+        assert np.array_equal(eng.lastcar[0].cpu().numpy(), g["lastcar"][t])
+        assert np.array_equal(eng.obs[0].cpu().numpy(), g["obs"][t])
+        assert np.array_equal(eng.rewards[0].cpu().numpy(), g["rewards"][t])
+    assert t == 120 and eng.pair_ticks() > 80
+
+
+def test_pairs_with_device_poisson_and_greedy():
+    """On-device Poisson arrivals and the greedy controller produce the second tick's inputs between the two
+    halves of a pair: same streams, same lights, same cars as tick by tick."""
+    E = 6
+    cfg = dict(m=4, n=3, length=150.0, capacity=20, rate=0.5)
+    a = pairs_engine(E, **cfg)
+    c = pertick_engine(E, **cfg)
+    for eng in (a, c):
+        eng.reset(np.zeros((E, eng.I), np.int32))
+        eng.set_poisson(0.9, seed=99)
+        eng.set_greedy(3)
+        eng.reset_counters()
+    for T in (3, 10, 4, 25, 7):
+        a.step(T)
+        c.step(T)
+        assert_engines_equal(a, c)
+    assert a.pair_ticks() > 30 and a.vehicle_updates() == c.vehicle_updates() > 0

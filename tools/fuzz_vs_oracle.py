@@ -1,6 +1,6 @@
 """Randomised differential test of the HIP path against the CPU oracle, for as long as FUZZ_SECS allows
 (default 420 s): random grid shape, capacity, road length, rate, learn_switch, validate, entry sides,
-batch size, car layout (ring / transposed), step path (LDS-resident k_res with 1-5 envs per workgroup / per-tick kernels), pathological or reset start
+batch size, car layout (ring / transposed), step path (LDS-resident k_res with 1-5 envs per workgroup / per-tick kernels / two-tick passes), pathological or reset start
 states, arrival density, uneven multi-tick calls.  Every call must leave the engine bit-equal to the
 oracle.  The RNG state at the start of the current case is kept in gpurun_out/fuzz_case_start.pkl:
 
@@ -26,7 +26,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT")}
+    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -56,6 +56,7 @@ def _run(rng, seed, LIMIT):
         os.environ["TFX_RESIDENT"] = "1" if mode == 1 else "0"      # LDS-resident multi-tick kernel | per-tick kernels
         os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))
         os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))    # lanes per road of k_res
+        os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))    # two-tick passes (k_move_tt + k_edge) forced at any size | never
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
         eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)
@@ -70,7 +71,7 @@ def _run(rng, seed, LIMIT):
             ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); eng.reset(ph); orc.reset(ph)
         dens = rng.choice([0.1, 0.6, 2.0]); t = 0; T = int(rng.choice([8, 30, 60]))
         while t < T:
-            k = int(min(T - t, rng.choice([1, 1, 2, 5, 10])))
+            k = int(min(T - t, rng.choice([1, 1, 2, 3, 4, 5, 10])))
             acts = rng.randint(2, size=(k, E, eng.I)).astype(np.int32)
             roads = [[(rng.choice(eng.entrypoints, size=rng.poisson(dens)).tolist() if eng.n_entry else []) for _ in range(E)] for _ in range(k)]
             eng.set_actions(acts, per_tick=True); eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
@@ -96,7 +97,7 @@ def _run(rng, seed, LIMIT):
                               "next ld/lc", (ldh[kk, nx], lch[kk, nx]) if nx >= 0 else None,
                               "phase/elapsed", eng.obs[kk, 2*eng.r + e % eng.I].item() if e < eng.r else None, eng.obs[kk, 2*eng.r + eng.I + e % eng.I].item() if e < eng.r else None,
                               "next tail gpu/orc", (st[0][kk][nx, lch[kk, nx]], orc.x[kk][nx, orc.lastcar[kk, nx]]) if nx >= 0 else None)
-            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, t))
+            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ["TFX_PAIRS"], t))
         if val:
             nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n
             for kk in range(E): assert np.array_equal(eng.trip_times[kk, :min(nt[kk], eng.trip_cap)].cpu().numpy(), orc.trip_times[kk, :min(nt[kk], eng.trip_cap)]), n

@@ -5,6 +5,8 @@
 // The reference's road-order rule is the same as in advance_road (tfx_advance.hpp): p's pushes see
 // leading[e] before e's own pops iff p < e.  A road that pops more than two cars, or a handed-off car
 // that would itself leave again in the same tick ("far"), sends the env to advance_env_serial_t.
+// After the second tick of a two-tick pass (k_edge, tfx_move_tt.hpp) a road that popped keeps its survivors
+// where they were: the rows of its column start rec_hb(rec.y) rows down, and so do the appends here.
 #pragma once
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
@@ -20,7 +22,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int k_e = rec_kpop(rc.x);
   float tail_x = __int_as_float(rc.z);
   const int ld_post = ring_adv(ld, k_e, C);
-  int m = rc.w - k_e;  // cars physically on the road after the move (positions 0 .. m-1)
+  int m = rec_hb(rc.y) + rc.w - k_e;  // first free row behind the cars physically on the road after the move
 
   int ovf = 0;
   const int p = d.pred[e];
@@ -83,6 +85,12 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
   else
     for (int e = 0; e < d.r; ++e) ob[e] -= rec_kpop(d.rec[env * d.R + e].x);
 
+  // what update_lights and add_car call the tail of a road is tracked in tailx from here on: the last car the
+  // move kernel processed (after a two-tick pass the rows themselves are already a tick ahead), then every push
+  for (int e = 0; e < d.R; ++e) d.tailx[env * d.R + e] = __int_as_float(d.rec[env * d.R + e].z);
+  // row k of a road's column, counted from its first live row
+  auto rowb = [&](int idq, int k) { return tpos(d, idq, k + rec_hb(d.rec[idq].y)); };
+
   // the j-th popped car of road `idq` while its pops are still pending
   auto popped = [&](int idq, int j, float &cw) {
     if (j >= KP) {  // (only an uncompacted road has that many)
@@ -104,17 +112,13 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int phys = ring_count(ldn, lcn, C) - pending;          // survivors + cars pushed so far
     const int base = (pending > 0 && rec_unc(rn.y)) ? pending : 0;  // rows the pending cars occupy
     const int pos = wrap1(lcn + 1, C);
-    float start = INFINITY;
-    if (lcn != ldn) {
-      float tx, dummy;
-      if (phys > 0) tx = d.xv[tpos(d, idn, base + phys - 1)].x;
-      else tx = popped(idn, pending - 1, dummy).x;
-      start = (tx - d.car_l) - d.car_s0;
-    }
+    const float start = (lcn != ldn) ? (d.tailx[idn] - d.car_l) - d.car_s0 : INFINITY;
     if (pos != ldn) {
-      d.xv[tpos(d, idn, base + phys)] = make_float2((start < car.x) ? start : car.x, car.y);
-      if (d.w) d.w[tpos(d, idn, base + phys)] = cw;
+      const float xv = (start < car.x) ? start : car.x;
+      d.xv[rowb(idn, base + phys)] = make_float2(xv, car.y);
+      if (d.w) d.w[rowb(idn, base + phys)] = cw;
       d.lastcar[idn] = pos;
+      d.tailx[idn] = xv;
     } else {
       if (nr < d.r) rew[nr % d.I] -= d.ovf_pen;
       overflowed = 1;
@@ -159,13 +163,14 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
       }
     }
     // cars pushed onto an (otherwise emptied) road that are themselves beyond its end
-    while (ld != d.lastcar[id] && d.xv[tpos(d, id, 0)].x > d.length) {
-      float2 car = d.xv[tpos(d, id, 0)];
-      const float cw = d.w ? d.w[tpos(d, id, 0)] : 0.0f;
+    // (a road with survivors never enters: its head stayed because x <= length, in either tick of a pass)
+    while (ld != d.lastcar[id] && d.xv[rowb(id, 0)].x > d.length) {
+      float2 car = d.xv[rowb(id, 0)];
+      const float cw = d.w ? d.w[rowb(id, 0)] : 0.0f;
       const int phys = ring_count(ld, d.lastcar[id], C);
       for (int q = 1; q < phys; ++q) {
-        d.xv[tpos(d, id, q - 1)] = d.xv[tpos(d, id, q)];
-        if (d.w) d.w[tpos(d, id, q - 1)] = d.w[tpos(d, id, q)];
+        d.xv[rowb(id, q - 1)] = d.xv[rowb(id, q)];
+        if (d.w) d.w[rowb(id, q - 1)] = d.w[rowb(id, q)];
       }
       ld = wrap1(ld + 1, C);
       d.leading[id] = ld;
@@ -178,11 +183,6 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
         trip(cw);
       }
     }
-  }
-  for (int e = 0; e < d.R; ++e) {
-    const int id = env * d.R + e;
-    const int n = ring_count(d.leading[id], d.lastcar[id], C);
-    d.tailx[id] = (n > 0) ? d.xv[tpos(d, id, n - 1)].x : 0.0f;
   }
   if (overflowed) d.done_tick[env] = tick + 1;
 }

@@ -49,7 +49,9 @@ struct Dev {
   const int *road_slot, *slot_road;
   int G;
   int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T: >= C - 2
-  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows | uncompacted << 30, bits of post-move tail x, live cars}
+  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows | head rows << 28 | uncompacted << 30, bits of post-move tail x, live cars}
+  int4 *rec2;     // per road, two-tick pass only (tfx_move_tt.hpp): {bits of the tail's v after the first tick, waiting and
+                  //   detected counts of the second tick so far, bits of the tail's x after the second tick}
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; the first TFX_KP = 2 cars that
   // left a road this tick wait in its outbox column outb[tile][j][64], j < KP - a road that pops more
   // stays uncompacted for the tick and its env takes the serial advance; the fake leader's x has no
@@ -259,8 +261,12 @@ __device__ __forceinline__ int rec_pack(int kpop, int ld, int C) { return kpop |
 __device__ __forceinline__ int rec_kpop(int rx) { return rx & 0xffff; }
 // rec.y: spawn overflows of the tick | "the road was left uncompacted" (transposed layout, > TFX_KP pops)
 __device__ __forceinline__ int rec_y(int ovf_sp, bool unc) { return ovf_sp | (unc ? (1 << 30) : 0); }
-__device__ __forceinline__ int rec_ovf_sp(int ry) { return ry & 0x3fffffff; }
+__device__ __forceinline__ int rec_ovf_sp(int ry) { return ry & 0x0fffffff; }
 __device__ __forceinline__ bool rec_unc(int ry) { return (ry >> 30) & 1; }
+// rec.y bits 28-29: rows at the top of the road's column that hold no car (transposed layout).  Only k_edge
+// leaves any: the second tick of a two-tick pass pops without compacting; the next move kernel of the same
+// call reads past them and writes the column compacted again (tfx_move_tt.hpp).
+__device__ __forceinline__ int rec_hb(int ry) { return (ry >> 28) & 3; }
 __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 
 // The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car

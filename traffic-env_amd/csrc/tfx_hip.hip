@@ -29,6 +29,7 @@
 #include "tfx_move_t.hpp"
 #include "tfx_move_t2.hpp"
 #include "tfx_move_ts.hpp"
+#include "tfx_move_tt.hpp"
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_misc.hpp"
@@ -64,6 +65,8 @@ struct tfx_handle_s {
   int n_cu = 256;
   int wpr = 1;
   int grid_move = 0;
+  int grid_tt[2] = {0, 0};    // k_move_tt<false>, k_move_tt<true>
+  int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
   int tiles_per_env = 0;      // G: 64-slot tiles one env occupies in the transposed layout
@@ -81,6 +84,7 @@ struct tfx_handle_s {
   std::vector<int> ev_weight;  // ticks the i-th timed entry covers (1, or the ticks of a fused launch)
   bool prof = false;
   long long fused_ticks = 0;   // ticks run by k_res since tfx_create
+  long long pair_ticks = 0;    // ticks run as two-tick passes since tfx_create
   const char *step_kernel = "";  // the kernel that moved the cars in the last tick (tfx_step_kernel)
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
@@ -460,6 +464,35 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   return TFX_OK;
 }
 
+// Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of three ticks or more on the transposed
+// layout whose launches fill the chip, outside validate mode (the spawn-tick plane does not travel) and
+// outside agent steps (an env that overflows in the first tick of a pair must stand still in the second).
+bool pairs_usable(tfx_handle h, int n_ticks) {
+  const Dev &d = h->d;
+  if (!h->pairs || d.layout != 1 || d.w || d.agent_mode || n_ticks < 3 || h->move_variant != 0) return false;
+  const long tiles = (long)d.E * d.G;
+  return h->pairs == 2 || tiles > (long)h->n_cu * 8;
+}
+
+template <bool TWO>
+int launch_move_tt(tfx_handle h, int tidx, hipStream_t st) {
+  int &grid = h->grid_tt[TWO ? 1 : 0];
+  if (grid == 0) grid = move_grid(h, k_move_tt<TWO>, 256);
+  h->step_kernel = "k_move_tt";
+  hipLaunchKernelGGL(k_move_tt<TWO>, dim3(grid), dim3(256), 0, st, h->d, tidx);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
+  const long tiles = (long)h->d.E * h->d.G;
+  long g = (tiles + 3) / 4;
+  if (g > (long)h->n_cu * 8) g = (long)h->n_cu * 8;
+  hipLaunchKernelGGL(k_edge, dim3((int)g), dim3(256), 0, st, h->d, tidx);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -578,6 +611,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   build_slots(h);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
+  if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -642,6 +676,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t ER = (size_t)d.E * R;
   size_t off = 0;
   const size_t o_rec = off;   off = align_up(off + ER * sizeof(int4), 256);
+  const size_t o_rec2 = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int4) : 0), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
   d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
@@ -666,6 +701,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   }
   char *base = (char *)h->dev_scratch;
   d.rec = (int4 *)(base + o_rec);
+  d.rec2 = (int4 *)(base + o_rec2);
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
   d.outb = (float2 *)(base + o_outb);
@@ -894,7 +930,45 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     }
     return TFX_OK;
   }
-  for (int t = 0; t < n_ticks; ++t) {
+  int t = 0;
+  if (pairs_usable(h, n_ticks)) {
+    // pairs of ticks, then one or two single ticks: the first of them (k_move_tt<false>) compacts the columns
+    // the last pair left with empty head rows, so the call ends in the layout every other kernel expects
+    for (; t + 2 < n_ticks; t += 2) {
+      const bool timed = h->prof && h->ev_used < h->ev_ticks;
+      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+      if (int rc = launch_inputs(h, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[0], st));
+      if (int rc = launch_move_tt<true>(h, t, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[1], st));
+      if (int rc = launch_advance(h, t, st)) return rc;
+      if (int rc = launch_inputs(h, st)) return rc;
+      if (int rc = launch_edge(h, t + 1, st)) return rc;
+      if (int rc = launch_advance(h, t + 1, st)) return rc;
+      if (timed) {
+        HIPCHK(hipEventRecord(e[2], st));
+        h->ev_weight[h->ev_used] = 2;
+        ++h->ev_used;
+      }
+      h->pair_ticks += 2;
+    }
+    {
+      const bool timed = h->prof && h->ev_used < h->ev_ticks;
+      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+      if (int rc = launch_inputs(h, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[0], st));
+      if (int rc = launch_move_tt<false>(h, t, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[1], st));
+      if (int rc = launch_advance(h, t, st)) return rc;
+      if (timed) {
+        HIPCHK(hipEventRecord(e[2], st));
+        h->ev_weight[h->ev_used] = 1;
+        ++h->ev_used;
+      }
+      ++t;
+    }
+  }
+  for (; t < n_ticks; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
     if (int rc = launch_inputs(h, st)) return rc;
@@ -1058,6 +1132,12 @@ int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->fused_ticks;
   if (capable) *capable = h->res_epb > 0 ? 1 : 0;
+  return TFX_OK;
+}
+
+int tfx_pair_ticks(tfx_handle h, int64_t *ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (ticks) *ticks = h->pair_ticks;
   return TFX_OK;
 }
 

@@ -1,0 +1,308 @@
+// tfx_move_tt.hpp - k_move_tt + k_edge: TWO ticks per pass over the cars (transposed layout).
+//
+// k_move_t reads and writes every live car once per tick and is bound by that traffic; its
+// vector ALU sits idle about a third of the time.  Under the Jacobi update a car's next state needs only
+// its own and its leader's current state, so while the walk of tick t holds the new states y(k-2), y(k-1)
+// of two consecutive cars in registers it can already take car k-1 through tick t+1 - z(k-1) - and store
+// THAT: two ticks of arithmetic for one trip of the cars through HBM.  What tick t+1 needs from OTHER
+// roads touches only the two ends of a column:
+//   * the head car follows the fake leader, whose x comes from the light state and the tail of the next
+//     road after tick t's handoff (update_lights :81-94);
+//   * cars handed over by tick t's advance, and cars spawned at tick t+1, queue behind the tail.
+// Those few cars ("deferred": the head and whatever joined behind the survivors) are left at their tick-t
+// state by the pass and taken through tick t+1 by k_edge, a lane-per-road kernel that runs after tick t's
+// k_advance: lights and spawns of t+1 (prep_road, unchanged), the deferred cars' IDM steps, the counts,
+// the pops of t+1 and the road record k_advance(t+1) consumes.  Launch sequence of a pair:
+//   k_move_tt<true>(t)  k_advance(t)  [inputs of t+1]  k_edge(t+1)  k_advance(t+1)
+// and the state after it is bit for bit the state after k_move_t, k_advance, k_move_t, k_advance - except
+// that a road that popped in t+1 is not compacted: its live rows start rec_hb(rec.y) rows down.  The next
+// move kernel of the same call (another pair, or k_move_tt<false>, the one-tick form) reads from there and
+// writes the column compacted; tfx_step always ends a call on the one-tick form, so nothing outside a call
+// ever sees such a column.
+//
+// Exactness notes: the interior cars' second step uses idm_step_fast under the same wave-wide domain test
+// as the first (both bit-identical to idm_step); k_edge uses idm_step.  The wrapped-ring quirk of the
+// waiting count (:210: x, not v, is tested on ring slots 1..lastcar) depends only on the head slot: car i
+// behind the head sits in slot leading+1+i, wrapped iff i >= C-1-leading, and an unwrapped ring has no
+// such car - so the pass can count tick t+1 before lastcar(t+1) is known.
+#pragma once
+#include <type_traits>
+
+#include "tfx_common.hpp"
+#include "tfx_move_t.hpp"
+
+namespace tfx {
+
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
+  constexpr int P = 4;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
+  const int C = d.C;
+  const long tiles = (long)d.E * d.G;
+  const long nw = (long)gridDim.x * 4;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
+    const int env = (int)(tile / d.G);  // a tile never straddles envs
+    const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+    const bool valid = e_slot >= 0;
+    const int e = valid ? e_slot : 0;
+    const int id = env * d.R + e;
+    const bool run = valid;  // (tfx_step only: envs are never frozen outside an agent step)
+    const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
+    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
+    const int n_old = run ? p.n_old : 0;
+    const int n_sp = run ? p.n_tot - p.n_old : 0;
+
+    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;  // written: row k of this road = col[k * 64]
+    const float2 *colr = col + (size_t)hb * 64;                 // read: the live rows start hb rows down
+    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+
+    int kmax = n_old;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(kmax, off, 64);
+      kmax = o > kmax ? o : kmax;
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+
+    float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
+    float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
+    int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
+    bool open = true, far = false;
+    bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
+    int shift = 0;
+    int kq1 = 0x7fffffff;  // tick t+1 tests x instead of v from this car on (index of tick t)
+    float tail_x = 0.0f, tail_v = 0.0f, tail_z = 0.0f;
+    const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
+
+    auto ld2 = [&](const float2 *ptr) {
+      const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ptr));
+      return make_float2(t.x, t.y);
+    };
+    auto st2 = [&](float2 *ptr, float a, float b) {
+      f2v t;
+      t.x = a;
+      t.y = b;
+      __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(ptr));
+    };
+    // Car k of this lane's road through tick t, car k-1 through tick t+1.  `last` (a compile-time flag): only
+    // the second half, for the road's last car.
+    auto step = [&](int k, float x, float v, auto last) {
+      constexpr bool LAST = decltype(last)::value;
+      float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
+      const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && !idm_fast_domain(y1v));
+      const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+      if (d.fastdiv && !off_domain) {
+        if (!LAST) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+        if (TWO) idm_step_fast(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
+      } else {
+        if (!LAST) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
+        if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
+      }
+      if (TWO && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
+        st2(&col[(size_t)(k - 1 - shift) * 64], pend_int ? zx : y1x, pend_int ? zv : y1v);
+        if (pend_int) {
+          const float wq1 = (k - 1 >= kq1) ? zx : zv;
+          n_wait1 += (wq1 < d.thresh) ? 1 : 0;
+          n_det1 += (zx > d.near_end) ? 1 : 0;
+          tail_z = zx;
+        }
+      }
+      if (LAST) return;
+      xprev = x;
+      vprev = v;
+      llv = d.car_l;
+      const bool was_open = open;
+      const bool pop = open && (xn > d.length);  // the while loop of :123
+      open = pop;
+      if (pop) {
+        if (kpop < KP) {
+          ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+          ++shift;
+        } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
+          shift = 0;
+          st2(&col[(size_t)k * 64], xn, vn);
+        }
+        far = far || ((xn - d.length) > d.length);
+        pend = false;
+      } else if (TWO) {
+        pend = true;
+        pend_int = !was_open;
+        if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
+      } else {
+        st2(&col[(size_t)(k - shift) * 64], xn, vn);
+      }
+      kpop += pop ? 1 : 0;
+      const float wq = (k >= kq) ? xn : vn;
+      n_wait += (wq < d.thresh) ? 1 : 0;
+      n_det += (xn > d.near_end) ? 1 : 0;
+      tail_x = xn;
+      tail_v = vn;
+      y2x = y1x;
+      y2v = y1v;
+      y1x = xn;
+      y1v = vn;
+    };
+
+    // ---- cars in memory: rows 0 .. kmax-1 of the live part, P rows in flight --------------------
+    float2 pf[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? ld2(&colr[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+    for (int k0 = 0; k0 < kmax; k0 += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int k = k0 + u;
+        if (k < kmax) {
+          const float2 cur = pf[u];
+          if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+          if (k < n_old) step(k, cur.x, cur.y, std::false_type{});
+        }
+      }
+    }
+    // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
+    if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
+      int smax = n_sp;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(smax, off, 64);
+        smax = o > smax ? o : smax;
+      }
+      smax = __builtin_amdgcn_readfirstlane(smax);
+      for (int s = 0; s < smax; ++s)
+        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, std::false_type{});
+    }
+    // ---- the road's last car through tick t+1 ----------------------------------------------------
+    if (TWO && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
+      if (pend) step(p.n_tot, 0.0f, 0.0f, std::true_type{});
+    }
+
+    // ---- phase W -------------------------------------------------------------------------------
+    if (run) {
+      const int n_tot = p.n_tot;
+      if (e < d.r) {
+        int *ob = d.obs + (size_t)env * d.obs_len;
+        if (n_tot > 0) {
+          d.waiting[(size_t)env * d.r + e] += n_wait;
+          ob[d.r + e] = n_det;
+        }
+        ob[e] = kpop;
+        if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+      }
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
+      if (TWO) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait1, n_det1, __float_as_int(tail_z));
+      if (far || kpop > KP) d.env_flag[env] = tick + 1;
+      d.leadx[id] = p.xL;
+      my_updates += (unsigned long long)n_tot;
+    }
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) veh_add(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+// The second tick of a pair for the cars k_move_tt<true> could not take through it (see the head of this
+// file).  Runs after k_advance of the first tick; same tile / lane ownership as the pass, a few cars per road.
+__global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
+  const int C = d.C;
+  const long tiles = (long)d.E * d.G;
+  const long nw = (long)gridDim.x * 4;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+
+  unsigned long long my_updates = 0;
+
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
+    const int env = (int)(tile / d.G);
+    const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+    if (e_slot < 0) continue;
+    const int e = e_slot;
+    const int id = env * d.R + e;
+    const int4 rc = d.rec[id];    // the pass's record of the first tick
+    const int4 r2 = d.rec2[id];
+    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, true, true);
+    const int m0 = rc.w - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
+    const int n_old = p.n_old, n_tot = p.n_tot;
+
+    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
+    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+
+    int kpop = 0, n_wait = (m0 >= 2) ? r2.y : 0, n_det = (m0 >= 2) ? r2.z : 0;
+    bool open = true, far = false;
+    const int kq = C - 1 - p.ld;
+    float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
+    float tail_x = 0.0f;
+    // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll)
+    auto car = [&](int i, float x, float v) {
+      float zx, zv;
+      idm_step(d, x, v, lx, lv, ll, zx, zv);
+      lx = x;
+      lv = v;
+      ll = d.car_l;
+      const bool pop = open && (zx > d.length);
+      open = pop;
+      if (pop && kpop < KP) ocol[(size_t)kpop * 64] = make_float2(zx, zv);
+      else col[(size_t)i * 64] = make_float2(zx, zv);  // (a popped car beyond the outbox stays in its row: uncompacted)
+      if (pop) far = far || ((zx - d.length) > d.length);
+      kpop += pop ? 1 : 0;
+      const float wq = (i >= kq) ? zx : zv;
+      n_wait += (wq < d.thresh) ? 1 : 0;
+      n_det += (zx > d.near_end) ? 1 : 0;
+      tail_x = zx;
+    };
+    if (m0 > 0) {
+      const float2 head = col[0];
+      car(0, head.x, head.y);
+      // cars behind a head that left: already a tick ahead, the pop prefix may run on into them
+      for (int i = 1; i < m0 && open; ++i) {
+        const float2 z = col[(size_t)i * 64];
+        if (z.x > d.length) {
+          if (kpop < KP) ocol[(size_t)kpop * 64] = z;
+          far = far || ((z.x - d.length) > d.length);
+          ++kpop;
+        } else {
+          open = false;
+        }
+      }
+      if (m0 >= 2) {  // whoever queues behind the survivors follows the last one's tick-t state
+        lx = __int_as_float(rc.z);
+        lv = __int_as_float(r2.x);
+        tail_x = __int_as_float(r2.w);
+      }
+    }
+    for (int i = m0; i < n_old; ++i) {  // handed over by the first tick's advance
+      const float2 c = col[(size_t)i * 64];
+      car(i, c.x, c.y);
+    }
+    for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v);  // spawned this tick
+
+    const bool unc = kpop > KP;
+    if (e < d.r) {
+      int *ob = d.obs + (size_t)env * d.obs_len;
+      if (n_tot > 0) {
+        d.waiting[(size_t)env * d.r + e] += n_wait;
+        ob[d.r + e] = n_det;
+      }
+      ob[e] = kpop;
+      if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+    }
+    d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
+                          __float_as_int(tail_x), n_tot);
+    if (far || unc) d.env_flag[env] = tick + 1;
+    d.leadx[id] = p.xL;
+    my_updates += (unsigned long long)n_tot;
+  }
+
+  for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
+  if (lane == 0 && my_updates) veh_add(d.veh, my_updates);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
+}
+
+}  // namespace tfx

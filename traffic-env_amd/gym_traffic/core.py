@@ -517,6 +517,12 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_fused_ticks(self.h, C.byref(n), C.byref(cap)))
         return int(n.value), bool(cap.value)
 
+    def pair_ticks(self):
+        """Ticks run so far as two-tick passes (k_move_tt + k_edge; tfx_pair_ticks)."""
+        n = C.c_int64()
+        nat.check(self.lib.tfx_pair_ticks(self.h, C.byref(n)))
+        return int(n.value)
+
     def step_kernel(self):
         """Name of the kernel that moved the cars in the last tick ('k_move_t', 'k_res', ...)."""
         return self.lib.tfx_step_kernel(self.h).decode()

@@ -66,6 +66,7 @@ struct tfx_handle_s {
   int wpr = 1;
   int grid_move = 0;
   int grid_tt[2] = {0, 0};    // k_move_tt<false>, k_move_tt<true>
+  int grid_edge = 0;
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
@@ -485,10 +486,16 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st) {
 }
 
 int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
-  const long tiles = (long)h->d.E * h->d.G;
-  long g = (tiles + 3) / 4;
-  if (g > (long)h->n_cu * 8) g = (long)h->n_cu * 8;
-  hipLaunchKernelGGL(k_edge, dim3((int)g), dim3(256), 0, st, h->d, tidx);
+  if (h->grid_edge == 0) {  // every block resident at once: a second, nearly empty round would double the time
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_edge, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (const char *pc = getenv("TFX_EDGE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+    const long tiles = (long)h->d.E * h->d.G;
+    long g = (long)h->n_cu * per_cu;
+    if (g > (tiles + 3) / 4) g = (tiles + 3) / 4;
+    h->grid_edge = (int)(g < 1 ? 1 : g);
+  }
+  hipLaunchKernelGGL(k_edge, dim3(h->grid_edge), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }

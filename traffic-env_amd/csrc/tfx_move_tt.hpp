@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
     int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
     bool open = true, far = false;
     bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
-    int shift = 0;
+    float2 *wp = col;  // where the next surviving car goes: one row further down per survivor
     int kq1 = 0x7fffffff;  // tick t+1 tests x instead of v from this car on (index of tick t)
     float tail_x = 0.0f, tail_v = 0.0f, tail_z = 0.0f;
     const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
         if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
       }
       if (TWO && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
-        st2(&col[(size_t)(k - 1 - shift) * 64], pend_int ? zx : y1x, pend_int ? zv : y1v);
+        st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
+        wp += 64;
         if (pend_int) {
           const float wq1 = (k - 1 >= kq1) ? zx : zv;
           n_wait1 += (wq1 < d.thresh) ? 1 : 0;
@@ -123,21 +124,20 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
       if (pop) {
         if (kpop < KP) {
           ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-          ++shift;
         } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
-          shift = 0;
           st2(&col[(size_t)k * 64], xn, vn);
+          wp = col + (size_t)(k + 1) * 64;
         }
         far = far || ((xn - d.length) > d.length);
-        pend = false;
+        ++kpop;
       } else if (TWO) {
         pend = true;
         pend_int = !was_open;
         if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
       } else {
-        st2(&col[(size_t)(k - shift) * 64], xn, vn);
+        st2(wp, xn, vn);
+        wp += 64;
       }
-      kpop += pop ? 1 : 0;
       const float wq = (k >= kq) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
       n_det += (xn > d.near_end) ? 1 : 0;
@@ -187,16 +187,16 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
       if (e < d.r) {
         int *ob = d.obs + (size_t)env * d.obs_len;
         if (n_tot > 0) {
-          d.waiting[(size_t)env * d.r + e] += n_wait;
+          if (!TWO) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
           ob[d.r + e] = n_det;
         }
-        ob[e] = kpop;
+        if (!TWO) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
-      if (TWO) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait1, n_det1, __float_as_int(tail_z));
+      if (TWO) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
-      d.leadx[id] = p.xL;
+      if (!TWO) d.leadx[id] = p.xL;  // (read by tfx_export_ring only; every call ends on the one-tick form)
       my_updates += (unsigned long long)n_tot;
     }
   }
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
     float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
 
-    int kpop = 0, n_wait = (m0 >= 2) ? r2.y : 0, n_det = (m0 >= 2) ? r2.z : 0;
+    // r2.y: the road's waiting count of the first tick plus the second tick's so far; r2.z: detected so far
+    int kpop = 0, n_wait = r2.y, n_det = r2.z;
     bool open = true, far = false;
     const int kq = C - 1 - p.ld;
     float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
@@ -286,17 +287,14 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
     const bool unc = kpop > KP;
     if (e < d.r) {
       int *ob = d.obs + (size_t)env * d.obs_len;
-      if (n_tot > 0) {
-        d.waiting[(size_t)env * d.r + e] += n_wait;
-        ob[d.r + e] = n_det;
-      }
+      if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
+      if (n_tot > 0) ob[d.r + e] = n_det;
       ob[e] = kpop;
       if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
     }
     d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
                           __float_as_int(tail_x), n_tot);
     if (far || unc) d.env_flag[env] = tick + 1;
-    d.leadx[id] = p.xL;
     my_updates += (unsigned long long)n_tot;
   }
 

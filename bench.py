@@ -276,6 +276,7 @@ def main():
     run(a.warmup)
     eng.profile_read()
     eng.reset_counters()
+    pair_ticks0 = eng.pair_ticks()
     fence()
     t0 = time.perf_counter()
     run(a.steps)
@@ -305,6 +306,11 @@ def main():
         tick_bytes = wl.algorithmic_bytes_per_tick(live_per_tick, E * eng.R, E * eng.I)
         achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
         kernel = eng.step_kernel()
+        # two-tick passes (k_move_tt + k_edge, csrc/tfx_move_tt.hpp) took the cars through most of the timed ticks
+        # (a call ends on one or two one-tick launches, which is what step_kernel() names)
+        pair_ticks = eng.pair_ticks() - pair_ticks0
+        if 2 * pair_ticks >= K:
+            kernel = "k_move_tt"
         traffic = load_pmc_traffic(a.config, kernel) if E == c["envs"] else None
         out = {
             "metric": "vehicle_updates_per_sec",
@@ -340,7 +346,12 @@ def main():
                          "algorithmic_bytes_per_launch": move_bytes, "launch_ms": move_ms,
                          # (k_res runs all the ticks of a tfx_step call in one launch: the figures above
                          # are per TICK of that launch)
-                         "ticks_per_launch": (GATHER_EVERY if gather is not None else K) if kernel == "k_res" else 1,
+                         # (k_move_tt: every car but the heads goes through TWO ticks per launch, so the HBM
+                         # traffic per tick is about half the algorithmic bytes and `frac` can exceed 1; `launch_ms`,
+                         # `achieved` and `traffic` are per TICK here too, `k_advance_ms` then also holds k_edge)
+                         "ticks_per_launch": ((GATHER_EVERY if gather is not None else K) if kernel == "k_res"
+                                              else 2 if kernel == "k_move_tt" else 1),
+                         "ticks_in_two_tick_passes": pair_ticks,
                          "launches_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,
                          "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -22,7 +22,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_t2", "k_move_t", "k_move")
+MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t2", "k_move_t", "k_move")
 
 
 def csrc_hash():
@@ -37,7 +37,9 @@ def csrc_hash():
 
 
 def short(name):
-    for k in MOVERS + ("k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
+    if "k_move_tt<false" in name:
+        return "k_move_tt1"          # the one-tick form that ends a call of two-tick passes
+    for k in MOVERS + ("k_edge", "k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
                        "k_poisson", "k_greedy", "k_agent_obs"):
         if k + "<" in name or k + "(" in name or name.strip().endswith(k):
             return k
@@ -56,7 +58,7 @@ def main():
     ap.add_argument("--note", default="")
     ap.add_argument("--kernel", default=None, help="the kernel whose traffic goes into pmc_<config>.json")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
-                    help="ticks one launch of that kernel covers (k_res: the n of tfx_step(n))")
+                    help="ticks one launch of that kernel covers (k_res: the n of tfx_step(n); k_move_tt: 2)")
     ap.add_argument("--hash", action="store_true", help="print the current csrc hash and exit")
     a = ap.parse_args()
     if a.hash:

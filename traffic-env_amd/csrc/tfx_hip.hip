@@ -67,6 +67,7 @@ struct tfx_handle_s {
   int grid_move = 0;
   int grid_tt[2] = {0, 0};    // k_move_tt<false>, k_move_tt<true>
   int grid_edge = 0;
+  bool pairs_pk = false;      // TFX_PAIRS_PK=1: the packed-pair arithmetic in the two-tick pass (A/B)
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
@@ -478,8 +479,14 @@ bool pairs_usable(tfx_handle h, int n_ticks) {
 template <bool TWO>
 int launch_move_tt(tfx_handle h, int tidx, hipStream_t st) {
   int &grid = h->grid_tt[TWO ? 1 : 0];
-  if (grid == 0) grid = move_grid(h, k_move_tt<TWO>, 256);
   h->step_kernel = "k_move_tt";
+  if (TWO && h->pairs_pk) {
+    if (grid == 0) grid = move_grid(h, k_move_tt<true, true>, 256);
+    hipLaunchKernelGGL((k_move_tt<true, true>), dim3(grid), dim3(256), 0, st, h->d, tidx);
+    HIPCHK(hipGetLastError());
+    return TFX_OK;
+  }
+  if (grid == 0) grid = move_grid(h, k_move_tt<TWO>, 256);
   hipLaunchKernelGGL(k_move_tt<TWO>, dim3(grid), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -489,6 +496,7 @@ int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
   if (h->grid_edge == 0) {  // every block resident at once: a second, nearly empty round would double the time
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_edge, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 6) per_cu = 6;  // measured at cfg2, 4 / 5 / 6 / 7 blocks per CU: 0.112 / 0.102 / 0.097 / 0.118 ms
     if (const char *pc = getenv("TFX_EDGE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
     const long tiles = (long)h->d.E * h->d.G;
     long g = (long)h->n_cu * per_cu;
@@ -619,6 +627,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
+  if (const char *pk = getenv("TFX_PAIRS_PK")) h->pairs_pk = atoi(pk) != 0;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

@@ -67,7 +67,6 @@ struct tfx_handle_s {
   int grid_move = 0;
   int grid_tt[2] = {0, 0};    // k_move_tt<false>, k_move_tt<true>
   int grid_edge = 0;
-  bool pairs_pk = false;      // TFX_PAIRS_PK=1: the packed-pair arithmetic in the two-tick pass (A/B)
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
@@ -480,12 +479,6 @@ template <bool TWO>
 int launch_move_tt(tfx_handle h, int tidx, hipStream_t st) {
   int &grid = h->grid_tt[TWO ? 1 : 0];
   h->step_kernel = "k_move_tt";
-  if (TWO && h->pairs_pk) {
-    if (grid == 0) grid = move_grid(h, k_move_tt<true, true>, 256);
-    hipLaunchKernelGGL((k_move_tt<true, true>), dim3(grid), dim3(256), 0, st, h->d, tidx);
-    HIPCHK(hipGetLastError());
-    return TFX_OK;
-  }
   if (grid == 0) grid = move_grid(h, k_move_tt<TWO>, 256);
   hipLaunchKernelGGL(k_move_tt<TWO>, dim3(grid), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
@@ -627,7 +620,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
-  if (const char *pk = getenv("TFX_PAIRS_PK")) h->pairs_pk = atoi(pk) != 0;
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

@@ -30,13 +30,10 @@
 
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
-#include "tfx_move_t2.hpp"
 
 namespace tfx {
 
-// PK: the two IDM steps of an iteration (car k through tick t, car k-1 through tick t+1) issue as ONE packed
-// pair (idm_pair, tfx_move_t2.hpp: v_pk_* arithmetic, v_max forms) under its wave-wide domain test
-template <bool TWO, bool PK = false>
+template <bool TWO>
 __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
   constexpr int P = 4;
   const int lane = threadIdx.x & 63;
@@ -46,8 +43,6 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-
-  const bool pk_ok = d.fastdiv && d.fastmax;
 
   unsigned long long my_updates = 0;
 
@@ -100,29 +95,6 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
     auto step = [&](int k, float x, float v, auto last) {
       constexpr bool LAST = decltype(last)::value;
       float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
-      if (PK && TWO && !LAST) {
-        v2f px, pv, pvl, pb, pxn, pvn;
-        px.x = x;
-        px.y = y1x;
-        pv.x = v;
-        pv.y = y1v;
-        pvl.x = vprev;
-        pvl.y = y2v;
-        pb.x = ((xprev - x) - llv) + d.eps;
-        pb.y = ((y2x - y1x) - d.car_l) + d.eps;
-        // (vprev and y2v were v and y1v of the previous iteration - tested there - or the fake leader's 0)
-        const bool ok = t2_v_ok(v) && t2_v_ok(y1v) && (__builtin_fabsf(pb.x) >= TFX_T2_B_LO) && (__builtin_fabsf(pb.y) >= TFX_T2_B_LO);
-        if (pk_ok && __builtin_amdgcn_ballot_w64(!ok) == 0ull) {
-          idm_pair(d, px, pv, pvl, pb, pxn, pvn);
-          xn = pxn.x;
-          zx = pxn.y;
-          vn = pvn.x;
-          zv = pvn.y;
-        } else {
-          idm_step(d, x, v, xprev, vprev, llv, xn, vn);
-          idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
-        }
-      } else {
       const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && !idm_fast_domain(y1v));
       const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
       if (d.fastdiv && !off_domain) {
@@ -131,7 +103,6 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
       } else {
         if (!LAST) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
         if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
-      }
       }
       if (TWO && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
         st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);

@@ -145,3 +145,46 @@ def test_pairs_with_device_poisson_and_greedy():
         c.step(T)
         assert_engines_equal(a, c)
     assert a.pair_ticks() > 30 and a.vehicle_updates() == c.vehicle_updates() > 0
+
+
+@pytest.mark.parametrize("C", [6, 20, 34])
+def test_pairs_full_rings_pop_and_receive_in_the_second_tick(C):
+    """Every ring full, every head a few metres short of the road end: heads leave in the SECOND tick of a pair
+    (k_edge leaves their columns starting one row down) while their predecessors hand cars over in the same
+    tick - the append must not run past the tile's last row (found by the fuzzer, seed 32 case 706: it landed
+    in the next tile's row 0)."""
+    rng = np.random.RandomState(3200 + C)
+    E, m, n, length = 6, 4, 4, 250.0
+    eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=1.0)
+    orc = oracle_like(eng)
+    for trial, T in enumerate([3, 4, 3, 6, 5]):
+        x = np.zeros((E, eng.R, C), np.float32)
+        v = np.zeros((E, eng.R, C), np.float32)
+        w = np.zeros((E, eng.R, C), np.float32)
+        leading = rng.randint(1, C, size=(E, eng.R)).astype(np.int32)
+        lastcar = leading.copy()
+        for k in range(E):
+            for e in range(eng.R):
+                cnt = C - 2 if rng.rand() < 0.8 else C - 3
+                head = length - rng.uniform(1.0, 14.0)
+                s = int(leading[k, e])
+                for j in range(cnt):
+                    s = s + 1 if s + 1 < C else 1
+                    x[k, e, s] = head - 5.5 * j
+                    v[k, e, s] = rng.uniform(3.0, 13.0)
+                lastcar[k, e] = s
+                x[k, e, leading[k, e]] = np.inf
+        phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        elapsed = rng.randint(6, 12, size=(E, eng.I)).astype(np.int32)      # (past yellow: half the lights are green)
+        load_both(eng, orc, x, v, w, leading, lastcar, phase, elapsed)
+        eng.set_tick(60)
+        orc.steps[:] = 60
+        acts = np.repeat(phase[None], T, 0)
+        roads = [[rng.choice(eng.entrypoints, size=rng.randint(0, 3)).tolist() for _ in range(E)] for _ in range(T)]
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+        eng.step(T)
+        for t in range(T):
+            orc.step(acts[t], roads[t])
+        assert_same_state(eng, orc, "C=%d trial %d (%d ticks)" % (C, trial, T))
+    assert eng.pair_ticks() > 0

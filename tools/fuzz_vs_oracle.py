@@ -9,7 +9,10 @@ oracle.  The RNG state at the start of the current case is kept in gpurun_out/fu
 
 Round 1: seed 11 found a race in the ring layout's advance (a popped road's fake-leader x was
 recomputed from obs words another lane of the same kernel was updating; fixed); seeds 12-15 and 21:
-24 500 cases clean."""
+24 500 cases clean.  Round 2, with the two-tick passes in the mix: seed 32 case 706 - a FULL ring whose head left
+in the second tick of a pair while its predecessor handed a car over: the append ran past the tile's last
+row into the next tile (fixed: tfx_advance_t.hpp compact_head_rows; pinned by tests/test_gpu_pairs.py);
+seeds 31-33 afterwards: 7 200 cases clean."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "traffic-env_amd"), os.path.join(ROOT, "tests")]
@@ -97,6 +100,19 @@ def _run(rng, seed, LIMIT):
                               "next ld/lc", (ldh[kk, nx], lch[kk, nx]) if nx >= 0 else None,
                               "phase/elapsed", eng.obs[kk, 2*eng.r + e % eng.I].item() if e < eng.r else None, eng.obs[kk, 2*eng.r + eng.I + e % eng.I].item() if e < eng.r else None,
                               "next tail gpu/orc", (st[0][kk][nx, lch[kk, nx]], orc.x[kk][nx, orc.lastcar[kk, nx]]) if nx >= 0 else None)
+            if os.environ.get("FUZZ_DEBUG"):
+                ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+                st = eng.planes_numpy()
+                for kk in range(E):
+                    for e in range(eng.R):
+                        cnt = (lch[kk, e] - ldh[kk, e]) % (C - 1)
+                        for i in range(cnt):
+                            sl = (ldh[kk, e] + i) % (C - 1) + 1
+                            for pl, nm, op in ((0, "x", orc.x), (1, "v", orc.v)):
+                                a, b = st[pl][kk][e, sl], op[kk][e, sl]
+                                if a.view(np.int32) != b.view(np.int32) and not (np.isnan(a) and np.isnan(b)):
+                                    print("DIFF tick", t, "k", k, "env", kk, "road", e, "car", i, "of", cnt, nm, "gpu", a, "oracle", b,
+                                          "pred", int(np.where(eng.nexts == e)[0][0]) if (eng.nexts == e).any() else -1, "next", int(eng.nexts[e]), flush=True)
             assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ["TFX_PAIRS"], t))
         if val:
             nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n

@@ -13,6 +13,13 @@
 
 namespace tfx {
 
+// A column whose live rows start `hb` rows down (left so by k_edge) has room for only trows - hb cars: before a
+// push would run past the tile's last row, move the n physical cars up to row 0 and clear the offset.
+__device__ __forceinline__ void compact_head_rows(const Dev &d, int id, int hb, int n) {
+  for (int q = 0; q < n; ++q) d.xv[tpos(d, id, q)] = d.xv[tpos(d, id, q + hb)];  // (never in validate mode: no w plane)
+  d.rec[id].y &= ~(3 << 28);
+}
+
 __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int C = d.C;
   const int id = env * d.R + e;
@@ -22,7 +29,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int k_e = rec_kpop(rc.x);
   float tail_x = __int_as_float(rc.z);
   const int ld_post = ring_adv(ld, k_e, C);
-  int m = rec_hb(rc.y) + rc.w - k_e;  // first free row behind the cars physically on the road after the move
+  int m = rc.w - k_e;  // cars physically on the road after the move
 
   int ovf = 0;
   const int p = d.pred[e];
@@ -30,6 +37,12 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
     const int idp = env * d.R + p;
     const int k_p = rec_kpop(d.rec[idp].x);
     if (k_p > 0) {
+      int hb = rec_hb(rc.y);
+      if (hb > 0 && hb + m + k_p > d.trows) {
+        compact_head_rows(d, id, hb, m);
+        hb = 0;
+      }
+      m += hb;  // first free row
       const int ld_seen = (p < e) ? ld : ld_post;
       const size_t pcol = ocol_of(d, env, p), ecol = tcol(d, env, e);
       for (int j = 0; j < k_p; ++j) {  // (k_p <= TFX_KP here: an env with a longer pop run takes the serial form)
@@ -113,6 +126,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int base = (pending > 0 && rec_unc(rn.y)) ? pending : 0;  // rows the pending cars occupy
     const int pos = wrap1(lcn + 1, C);
     const float start = (lcn != ldn) ? (d.tailx[idn] - d.car_l) - d.car_s0 : INFINITY;
+    if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
     if (pos != ldn) {
       const float xv = (start < car.x) ? start : car.x;
       d.xv[rowb(idn, base + phys)] = make_float2(xv, car.y);

@@ -13,12 +13,14 @@ from gym_traffic import workload as wl  # noqa: E402
 from gym_traffic.core import TfxEngine  # noqa: E402
 
 
-@pytest.fixture(params=["resident", "pertick"], autouse=True)
+@pytest.fixture(params=["resident", "pertick", "pairs"], autouse=True)
 def step_path(request, monkeypatch):
     """Both forms of the fused decision: every tick in one LDS-resident launch (k_res, 3 envs per
     workgroup) and the captured sequence of per-tick kernels."""
     monkeypatch.setenv("TFX_RESIDENT", "1" if request.param == "resident" else "0")
     monkeypatch.setenv("TFX_RES_EPB", "3")
+    # "pairs": two ticks per pass over the cars (k_move_tt + k_edge, k_risk inside agent steps), forced at test sizes
+    monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
     yield request.param
 
 

@@ -14,13 +14,15 @@ from gym_traffic.core import TfxEngine  # noqa: E402
 from gym_traffic.devrng import PoissonMirror, gap_table, philox4x32  # noqa: E402
 
 
-@pytest.fixture(params=["resident", "pertick"], autouse=True)
+@pytest.fixture(params=["resident", "pertick", "pairs"], autouse=True)
 def step_path(request, monkeypatch):
     """Both producers of the on-device inputs: inside the LDS-resident kernel k_res (Poisson stream and
     greedy rule evaluated in the kernel, 2 envs per workgroup) and the per-tick kernels k_poisson /
     k_greedy."""
     monkeypatch.setenv("TFX_RESIDENT", "1" if request.param == "resident" else "0")
     monkeypatch.setenv("TFX_RES_EPB", "2")
+    # "pairs": two ticks per pass over the cars (k_move_tt + k_edge, k_risk inside agent steps), forced at test sizes
+    monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
     yield request.param
 
 

@@ -18,10 +18,11 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     L = float(rng.choice([40.0, 90.0, 150.0, 250.0]))
     E = int(rng.choice([1, 3, 7, 33]))
     layout = str(rng.choice(["ring", "transposed"]))
-    remi = bool(rng.randint(2)); T = int(rng.choice([2, 5, 10])); period = int(rng.choice([1, 2, 5, 9]))
+    remi = bool(rng.randint(2)); T = int(rng.choice([2, 3, 4, 5, 10])); period = int(rng.choice([1, 2, 5, 9]))
     os.environ["TFX_RESIDENT"] = str(int(rng.randint(3) > 0))     # the LDS-resident k_res (2 in 3) | per-tick kernels
     os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 4])))
     os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))
+    os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))     # two-tick passes + k_risk forced at any size | never
     eng = TfxEngine(m, nn, L, C, n_envs=E, planes=2 if layout == "transposed" else 3, layout=layout)
     orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
     ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)

@@ -62,6 +62,7 @@ struct Dev {
   int layout;
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
   int *env_flag;  // == tick+1 when the env must take the serial advance this tick
+  int *env_risk;  // == tick+1 when the env takes the pair of ticks starting at `tick` one tick at a time (k_risk)
   unsigned long long *veh;
   int *tickA, *tickB;
   // per-tick inputs

@@ -65,7 +65,7 @@ struct tfx_handle_s {
   int n_cu = 256;
   int wpr = 1;
   int grid_move = 0;
-  int grid_tt[2] = {0, 0};    // k_move_tt<false>, k_move_tt<true>
+  int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
@@ -466,29 +466,18 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
 }
 
 // Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of three ticks or more on the transposed
-// layout whose launches fill the chip, outside validate mode (the spawn-tick plane does not travel) and
-// outside agent steps (an env that overflows in the first tick of a pair must stand still in the second).
+// layout whose launches fill the chip, outside validate mode (the spawn-tick plane does not travel).
 bool pairs_usable(tfx_handle h, int n_ticks) {
   const Dev &d = h->d;
-  if (!h->pairs || d.layout != 1 || d.w || d.agent_mode || n_ticks < 3 || h->move_variant != 0) return false;
+  if (!h->pairs || d.layout != 1 || d.w || n_ticks < 3 || h->move_variant != 0) return false;
   const long tiles = (long)d.E * d.G;
   return h->pairs == 2 || tiles > (long)h->n_cu * 8;
 }
 
-template <bool TWO>
-int launch_move_tt(tfx_handle h, int tidx, hipStream_t st) {
-  int &grid = h->grid_tt[TWO ? 1 : 0];
-  h->step_kernel = "k_move_tt";
-  if (grid == 0) grid = move_grid(h, k_move_tt<TWO>, 256);
-  hipLaunchKernelGGL(k_move_tt<TWO>, dim3(grid), dim3(256), 0, st, h->d, tidx);
-  HIPCHK(hipGetLastError());
-  return TFX_OK;
-}
-
-int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
+int edge_grid(tfx_handle h) {
   if (h->grid_edge == 0) {  // every block resident at once: a second, nearly empty round would double the time
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_edge, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_edge<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 6) per_cu = 6;  // measured at cfg2, 4 / 5 / 6 / 7 blocks per CU: 0.112 / 0.102 / 0.097 / 0.118 ms
     if (const char *pc = getenv("TFX_EDGE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
     const long tiles = (long)h->d.E * h->d.G;
@@ -496,7 +485,30 @@ int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
     if (g > (tiles + 3) / 4) g = (tiles + 3) / 4;
     h->grid_edge = (int)(g < 1 ? 1 : g);
   }
-  hipLaunchKernelGGL(k_edge, dim3(h->grid_edge), dim3(256), 0, st, h->d, tidx);
+  return h->grid_edge;
+}
+
+// AGENT: inside an agent step; only_risky: the second tick of the envs k_risk sorted out of a pair
+template <bool TWO, bool AGENT = false>
+int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
+  int &grid = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
+  if (grid == 0) grid = move_grid(h, k_move_tt<TWO, AGENT>, 256);
+  h->step_kernel = "k_move_tt";
+  if (h->size_only) return TFX_OK;
+  hipLaunchKernelGGL((k_move_tt<TWO, AGENT>), dim3(grid), dim3(256), 0, st, h->d, tidx, only_risky);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+template <bool AGENT>
+int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
+  hipLaunchKernelGGL(k_edge<AGENT>, dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int launch_risk(tfx_handle h, int tidx, hipStream_t st) {
+  hipLaunchKernelGGL(k_risk, dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -526,7 +538,28 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
   {
-    for (int t = 0; t < n_ticks && rc == TFX_OK; ++t) {
+    int t = 0;
+    if (pairs_usable(h, n_ticks)) {
+      // two-tick passes (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
+      // tick at a time (k_risk); the step ends on the one-tick form, which also compacts what the pairs left
+      for (; t + 2 < n_ticks && rc == TFX_OK; t += 2) {
+        rc = launch_inputs(h, st);
+        if (rc == TFX_OK) rc = launch_risk(h, t, st);
+        if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
+        if (rc == TFX_OK) rc = launch_advance(h, t, st);
+        if (rc == TFX_OK) rc = launch_inputs(h, st);
+        if (rc == TFX_OK) rc = launch_edge<true>(h, t + 1, st);
+        if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 1);
+        if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
+        if (rc == TFX_OK) h->pair_ticks += 2;
+      }
+      for (; t < n_ticks && rc == TFX_OK; ++t) {
+        rc = launch_inputs(h, st);
+        if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t, st);
+        if (rc == TFX_OK) rc = launch_advance(h, t, st);
+      }
+    }
+    for (; t < n_ticks && rc == TFX_OK; ++t) {
       rc = launch_inputs(h, st);
       if (rc == TFX_OK) rc = launch_move(h, t, st);
       if (rc == TFX_OK) rc = launch_advance(h, t, st);
@@ -578,6 +611,13 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     if (!h->ag_stream) HIPCHK(hipStreamCreateWithFlags(&h->ag_stream, hipStreamNonBlocking));
     if (h->grid_move == 0 && !res_usable(h, n_ticks)) {  // size the move grid outside the capture (occupancy queries)
       if (int rc = launch_move_probe(h)) return rc;
+    }
+    if (!res_usable(h, n_ticks) && pairs_usable(h, n_ticks)) {
+      h->size_only = true;
+      (void)launch_move_tt<true, true>(h, 0, nullptr);
+      (void)launch_move_tt<false, true>(h, 0, nullptr);
+      h->size_only = false;
+      (void)edge_grid(h);
     }
     HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
     const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream);
@@ -687,6 +727,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec2 = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int4) : 0), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
+  const size_t o_risk = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
   d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
   // outbox: TFX_KP rows per tile (the cars a road hands over in a tick; round 1 kept a T-sized one)
@@ -712,6 +753,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.rec2 = (int4 *)(base + o_rec2);
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
+  d.env_risk = (int *)(base + o_risk);
   d.outb = (float2 *)(base + o_outb);
   d.outw = (float *)(base + o_outw);
   d.leadx = (float *)(base + o_lead);
@@ -951,7 +993,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
       if (timed) HIPCHK(hipEventRecord(e[1], st));
       if (int rc = launch_advance(h, t, st)) return rc;
       if (int rc = launch_inputs(h, st)) return rc;
-      if (int rc = launch_edge(h, t + 1, st)) return rc;
+      if (int rc = launch_edge<false>(h, t + 1, st)) return rc;
       if (int rc = launch_advance(h, t + 1, st)) return rc;
       if (timed) {
         HIPCHK(hipEventRecord(e[2], st));

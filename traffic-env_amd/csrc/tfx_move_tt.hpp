@@ -25,6 +25,16 @@
 // waiting count (:210: x, not v, is tested on ring slots 1..lastcar) depends only on the head slot: car i
 // behind the head sits in slot leading+1+i, wrapped iff i >= C-1-leading, and an unwrapped ring has no
 // such car - so the pass can count tick t+1 before lastcar(t+1) is known.
+//
+// Agent steps (tfx_agent_step: an env that overflows stands still for the rest of the step) use the pairs too.
+// The pass has already moved the interior cars of tick t+1 when tick t's advance discovers an overflow, so envs
+// in which tick t COULD overflow are sorted out beforehand: k_risk marks an env "risky" when some ring could run
+// full this tick - its cars + its arrivals + the cars its predecessor can hand over exceed the ring - or when a
+// road could pop more than TFX_KP cars or hand over a car that runs through the whole next road (then the number
+// of pushes is not bounded by TFX_KP).  "Can pop" is a bound, not the IDM result: a car moves at most
+// rate*v + a*rate^2/2 per tick because the acceleration never exceeds a.  Risky envs take both ticks of the pair
+// one at a time (the pass treats their tiles as the one-tick form, k_edge skips them, a one-tick launch
+// restricted to them follows); every other env provably has no overflow in tick t.
 #pragma once
 #include <type_traits>
 
@@ -33,8 +43,11 @@
 
 namespace tfx {
 
-template <bool TWO>
-__global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
+// AGENT: inside an agent step - frozen envs are skipped, `passed` accumulates over the step, tiles of risky
+// envs (env_risk == tick + 1) take the one-tick form; only_risky: nothing but the tiles of envs marked risky
+// for the pair that began one tick earlier (the second tick of those envs)
+template <bool TWO, bool AGENT = false>
+__global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
   constexpr int P = 4;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -48,11 +61,25 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
 
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);  // a tile never straddles envs
+    if (AGENT && only_risky && d.env_risk[env] != tick) continue;
+    // this tile goes through two ticks (wave-uniform)
+    const bool two = TWO && !(AGENT && d.env_risk[env] == tick + 1);
     const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
     const bool valid = e_slot >= 0;
     const int e = valid ? e_slot : 0;
     const int id = env * d.R + e;
-    const bool run = valid;  // (tfx_step only: envs are never frozen outside an agent step)
+    const bool run = valid && !(AGENT && env_frozen(d, env, tick));
+    if (AGENT && !TWO && valid && !run) {
+      // an env that overflowed in the SECOND tick of a pair stands still from then on, its columns as k_edge
+      // left them: the one-tick form that ends the step moves them up so that nothing outside the step sees them
+      const int fb = rec_hb(d.rec[id].y);
+      if (fb > 0) {
+        float2 *fc = d.xv + ((size_t)tile * d.trows) * 64 + lane;
+        const int fn = ring_count(d.leading[id], d.lastcar[id], C);
+        for (int q = 0; q < fn; ++q) fc[(size_t)q * 64] = fc[(size_t)(q + fb) * 64];
+        d.rec[id].y &= ~(3 << 28);
+      }
+    }
     const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
     const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
     const int n_old = run ? p.n_old : 0;
@@ -95,7 +122,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
     auto step = [&](int k, float x, float v, auto last) {
       constexpr bool LAST = decltype(last)::value;
       float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
-      const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && !idm_fast_domain(y1v));
+      const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v));
       const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
       if (d.fastdiv && !off_domain) {
         if (!LAST) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
         if (!LAST) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
         if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
       }
-      if (TWO && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
+      if (TWO && two && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
         st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
         wp += 64;
         if (pend_int) {
@@ -130,7 +157,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
         }
         far = far || ((xn - d.length) > d.length);
         ++kpop;
-      } else if (TWO) {
+      } else if (TWO && two) {
         pend = true;
         pend_int = !was_open;
         if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
         if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, std::false_type{});
     }
     // ---- the road's last car through tick t+1 ----------------------------------------------------
-    if (TWO && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
+    if (TWO && two && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
       if (pend) step(p.n_tot, 0.0f, 0.0f, std::true_type{});
     }
 
@@ -187,16 +214,17 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
       if (e < d.r) {
         int *ob = d.obs + (size_t)env * d.obs_len;
         if (n_tot > 0) {
-          if (!TWO) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
+          if (!two) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
           ob[d.r + e] = n_det;
         }
-        if (!TWO) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
+        if (AGENT) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;  // accumulates over the agent step
+        else if (!two) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
-      if (TWO) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
+      if (two) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
-      if (!TWO) d.leadx[id] = p.xL;  // (read by tfx_export_ring only; every call ends on the one-tick form)
+      if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only; every call ends on the one-tick form)
       my_updates += (unsigned long long)n_tot;
     }
   }
@@ -206,8 +234,51 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
 }
 
+// Before a pair inside an agent step: marks the envs in which the pair's first tick could overflow a ring or
+// pop / hand over more cars than the pair's bookkeeping assumes (see the head of this file).
+__global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
+  const int C = d.C;
+  const long tiles = (long)d.E * d.G;
+  const long nw = (long)gridDim.x * 4;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+  // the farthest a car can move in a tick beyond rate * v: the IDM acceleration is at most a (:56-57)
+  const float half_ar2 = (0.5f * (d.car_a * d.rate)) * d.rate;
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
+    const int env = (int)(tile / d.G);
+    if (env_frozen(d, env, tick)) continue;
+    const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+    if (e < 0) continue;
+    const int id = env * d.R + e;
+    const int n = ring_count(d.leading[id], d.lastcar[id], C);
+    const int ej = d.entry_idx[e];
+    const int c_sp = ej >= 0 ? spawn_count(d, env, e, ej, tick_sp, tidx) : 0;
+    bool risky = n + c_sp > C - 2;
+    // how many cars could leave: a prefix of the cars that can reach the end of the road at all
+    const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)rec_hb(d.rec[id].y) * 64;
+    int pops = 0;
+    for (int j = 0; j <= KP && j < n; ++j) {
+      const float2 c = col[(size_t)j * 64];
+      const float reach = c.x + __builtin_fmaxf(d.rate * c.y + half_ar2, 0.0f);
+      if (!(reach > d.length)) break;
+      ++pops;
+      if ((reach - d.length) > d.length) risky = true;  // could run through the next road as well
+    }
+    if (pops > KP) risky = true;
+    const int nx = d.nexts[e];
+    if (pops > 0 && nx >= 0) {
+      const int idn = env * d.R + nx;
+      if (ring_count(d.leading[idn], d.lastcar[idn], C) + pops > C - 2) risky = true;
+    }
+    if (risky) d.env_risk[env] = tick + 1;
+  }
+}
+
 // The second tick of a pair for the cars k_move_tt<true> could not take through it (see the head of this
 // file).  Runs after k_advance of the first tick; same tile / lane ownership as the pass, a few cars per road.
+template <bool AGENT>
 __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,6 +292,9 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
 
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);
+    // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
+    // one-tick launch of their own)
+    if (AGENT && (d.env_risk[env] == tick || env_frozen(d, env, tick))) continue;
     const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
     if (e_slot < 0) continue;
     const int e = e_slot;
@@ -289,7 +363,7 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
       int *ob = d.obs + (size_t)env * d.obs_len;
       if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
       if (n_tot > 0) ob[d.r + e] = n_det;
-      ob[e] = kpop;
+      ob[e] = AGENT ? ob[e] + kpop : kpop;
       if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
     }
     d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),

@@ -188,3 +188,37 @@ def test_pairs_full_rings_pop_and_receive_in_the_second_tick(C):
             orc.step(acts[t], roads[t])
         assert_same_state(eng, orc, "C=%d trial %d (%d ticks)" % (C, trial, T))
     assert eng.pair_ticks() > 0
+
+
+@pytest.mark.parametrize("m,n,C,length", [(2, 2, 10, 60.0), (4, 4, 20, 250.0), (3, 2, 34, 200.0), (2, 2, 130, 800.0)])
+@pytest.mark.parametrize("remi", [False, True])
+def test_agent_steps_in_pairs_on_pathological_states(m, n, C, length, remi):
+    """tfx_agent_step over two-tick passes == tick by tick, from states where the first tick of a pair overflows
+    rings, pops more than two cars per road or sends cars through a whole road (k_risk must sort those envs
+    out: an env that overflows stands still for the rest of the step), and where the SECOND tick overflows (the
+    env freezes with columns k_edge left uncompacted: the step's last launch moves them up)."""
+    rng = np.random.RandomState(555 + C + int(remi))
+    E = 12
+    a = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    c = pertick_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    froze = 0
+    for trial, T in enumerate([3, 10, 4, 5, 10, 7]):
+        x, v, w, leading, lastcar = random_state(rng, E, a.R, C, length, crowd=rng.choice([0.5, 0.9]),
+                                                 beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=bool(trial % 2))
+        phase = rng.randint(2, size=(E, a.I)).astype(np.int32)
+        act = rng.randint(2, size=(E, a.I)).astype(np.int32)
+        period = int(rng.choice([1, 2, 5]))
+        for eng in (a, c):
+            eng.reset(phase)
+            eng.load_state(x, v, leading, lastcar)
+            eng.set_tick(40)
+            eng.set_spawns(period=period)
+            eng.set_actions(act)
+        for step in range(3):      # (an env that overflowed simply goes on in the next step, as a caller that does not reset it would)
+            ra = [t.clone() for t in a.agent_step(T, remi=remi)]
+            rc = [t.clone() for t in c.agent_step(T, remi=remi)]
+            for u, w_ in zip(ra, rc):
+                assert torch.equal(u, w_), (trial, step)
+            assert_engines_equal(a, c)
+            froze += int(ra[2].sum())
+    assert a.pair_ticks() > 0 and c.pair_ticks() == 0 and froze > 0

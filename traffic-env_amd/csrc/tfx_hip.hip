@@ -470,8 +470,11 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
 bool pairs_usable(tfx_handle h, int n_ticks) {
   const Dev &d = h->d;
   if (!h->pairs || d.layout != 1 || d.w || n_ticks < 3 || h->move_variant != 0) return false;
+  // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
+  // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
+  // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
   const long tiles = (long)d.E * d.G;
-  return h->pairs == 2 || tiles > (long)h->n_cu * 8;
+  return h->pairs == 2 || tiles >= (long)h->n_cu * 4;
 }
 
 int edge_grid(tfx_handle h) {

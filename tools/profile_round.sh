@@ -22,8 +22,10 @@ for cfg in cfg2 cfg1 cfg4; do
   prof ${cfg}_write --kernel-trace --pmc WRITE_SIZE -- --config $cfg
   prof ${cfg}_sq --kernel-trace --pmc $SQ -- --config $cfg
 done
-TFX_MOVE_VARIANT=104 prof cfg2_t2_sq --kernel-trace --pmc $SQ -- --config cfg2
-TFX_MOVE_VARIANT=104 prof cfg2_t2_kt --kernel-trace --stats -- --config cfg2
+# the tick-by-tick kernels next to the two-tick passes (k_move_t's own numbers)
+TFX_PAIRS=0 prof cfg2_pertick_kt --kernel-trace --stats -- --config cfg2
+TFX_PAIRS=0 prof cfg2_pertick_fetch --kernel-trace --pmc FETCH_SIZE -- --config cfg2
+TFX_PAIRS=0 prof cfg2_pertick_write --kernel-trace --pmc WRITE_SIZE -- --config cfg2
 TFX_RESIDENT=0 prof cfg1_pertick_kt --kernel-trace --stats -- --config cfg1
 cd $R
 # (cfg0 / cfg1: k_res runs the whole timed region as ONE launch of 2 ms per 200 ticks: timed over 2000)
@@ -32,9 +34,12 @@ for cfg in cfg2 cfg1 cfg0 cfg4; do
   python3 bench.py --config $cfg --steps $ST --warmup $WU $( [ $cfg = cfg2 ] || echo --no-cpu-baseline ) > $O/bench_$cfg.json 2> $O/bench_$cfg.err
   echo "bench $cfg: $(python3 -c "import json;d=json.load(open('$O/bench_$cfg.json'));print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'])")"
 done
+TFX_PAIRS=0 python3 bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_pertick.json 2>/dev/null
+TFX_PAIRS=0 python3 bench.py --config cfg4 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg4_pertick.json 2>/dev/null
 TFX_RESIDENT=0 python3 bench.py --config cfg1 --steps 200 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_pertick.json 2>/dev/null
 python3 bench.py --config cfg1 --envs 4096 --steps 1000 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_4096.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 256 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_256.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg2_32768.json 2>/dev/null
 ( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt
+( python3 tools/bench_agent_step.py cfg2; TFX_PAIRS=0 python3 tools/bench_agent_step.py cfg2 ) 2>&1 | grep -v amdgpu.ids > $O/agent_step_cfg2.txt
 echo finished

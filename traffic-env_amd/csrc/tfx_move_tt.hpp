@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
     bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
     float2 *wp = col;  // where the next surviving car goes: one row further down per survivor
     int kq1 = 0x7fffffff;  // tick t+1 tests x instead of v from this car on (index of tick t)
-    float tail_x = 0.0f, tail_v = 0.0f, tail_z = 0.0f;
+    float tail_x = 0.0f, tail_z = 0.0f;
     const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
 
     auto ld2 = [&](const float2 *ptr) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
           const float wq1 = (k - 1 >= kq1) ? zx : zv;
           n_wait1 += (wq1 < d.thresh) ? 1 : 0;
           n_det1 += (zx > d.near_end) ? 1 : 0;
-          tail_z = zx;
+          if (LAST) tail_z = zx;  // (the road's last car is flushed by the LAST call)
         }
       }
       if (LAST) return;
@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
       const float wq = (k >= kq) ? xn : vn;
       n_wait += (wq < d.thresh) ? 1 : 0;
       n_det += (xn > d.near_end) ? 1 : 0;
-      tail_x = xn;
-      tail_v = vn;
+      if (!TWO) tail_x = xn;  // (a pair: y1 holds the last car's new state when the walk ends)
       y2x = y1x;
       y2v = y1v;
       y1x = xn;
@@ -221,8 +220,9 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
         else if (!two) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
+      if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
-      if (two) d.rec2[id] = make_int4(__float_as_int(tail_v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
+      if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
       if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only; every call ends on the one-tick form)
       my_updates += (unsigned long long)n_tot;

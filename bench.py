@@ -311,7 +311,8 @@ def main():
         pair_ticks = eng.pair_ticks() - pair_ticks0
         if 2 * pair_ticks >= K:
             kernel = "k_move_tt"
-        traffic = load_pmc_traffic(a.config, kernel) if E == c["envs"] else None
+        traffic = load_pmc_traffic(a.config, kernel) if E == c["envs"] else None      # HBM bytes per TICK
+        tpl = ((GATHER_EVERY if gather is not None else K) if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)
         out = {
             "metric": "vehicle_updates_per_sec",
             "value": total_updates / dt_max,
@@ -335,24 +336,26 @@ def main():
             "env_steps_per_sec": world * E * K / dt_max,
             "agent_steps_per_sec": world * E * K / dt_max / GATHER_EVERY,   # one decision = 10 ticks
             "mean_live_cars_per_road": live_per_tick / (E * eng.R),
+            # One launch of k_res covers all the ticks of a tfx_step call, one launch of k_move_tt two: the
+            # per-launch figures are the per-tick ones times `ticks_per_launch` (`per_tick` keeps the latter).
+            # k_move_tt takes every car but the heads through TWO ticks per trip through HBM, so its HBM traffic is
+            # about half the algorithmic bytes and `frac`, defined on the algorithmic bytes, exceeds 1: the
+            # launch is bound by vector-ALU issue, not by the 8 TB/s; `k_advance_ms` then also
+            # holds k_edge, the second tick of the road heads.
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic * tpl if traffic else None,
                          # the PMC bytes over the live launch time, and that rate against the part's
                          # measured streaming ceiling (informative; `frac` above is against the 8 TB/s spec)
                          "traffic_rate_GBs": traffic / (move_ms * 1e-3) / 1e9 if traffic and move_ms > 0 else None,
                          "traffic_frac_of_measured_stream_peak": traffic / (move_ms * 1e-3) / 1e9 / HBM_STREAM_GBS
                          if traffic and move_ms > 0 else None,
-                         "algorithmic_bytes_per_launch": move_bytes, "launch_ms": move_ms,
-                         # (k_res runs all the ticks of a tfx_step call in one launch: the figures above
-                         # are per TICK of that launch)
-                         # (k_move_tt: every car but the heads goes through TWO ticks per launch, so the HBM
-                         # traffic per tick is about half the algorithmic bytes and `frac` can exceed 1; `launch_ms`,
-                         # `achieved` and `traffic` are per TICK here too, `k_advance_ms` then also holds k_edge)
-                         "ticks_per_launch": ((GATHER_EVERY if gather is not None else K) if kernel == "k_res"
-                                              else 2 if kernel == "k_move_tt" else 1),
+                         "algorithmic_bytes_per_launch": move_bytes * tpl, "launch_ms": move_ms * tpl,
+                         "ticks_per_launch": tpl,
+                         "per_tick": {"algorithmic_bytes": move_bytes, "launch_ms": move_ms, "traffic": traffic,
+                                      "k_advance_ms": adv_ms},
                          "ticks_in_two_tick_passes": pair_ticks,
-                         "launches_timed": prof["ticks"], "k_advance_ms": adv_ms,
+                         "ticks_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,
                          "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
                          if move_ms + adv_ms > 0 else 0.0},

@@ -16,6 +16,8 @@ prof() {  # name, rocprof args..., -- bench args
   rocprofv3 "${rargs[@]}" -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $O/$name.log 2>&1 || echo "FAILED $name"
   echo "done $name"
 }
+# BENCH_ONLY=1: only the un-profiled bench lines below
+[ "${BENCH_ONLY:-0}" = 1 ] || {
 for cfg in cfg2 cfg1 cfg4; do
   prof ${cfg}_kt --kernel-trace --stats -- --config $cfg
   prof ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -- --config $cfg
@@ -27,6 +29,7 @@ TFX_PAIRS=0 prof cfg2_pertick_kt --kernel-trace --stats -- --config cfg2
 TFX_PAIRS=0 prof cfg2_pertick_fetch --kernel-trace --pmc FETCH_SIZE -- --config cfg2
 TFX_PAIRS=0 prof cfg2_pertick_write --kernel-trace --pmc WRITE_SIZE -- --config cfg2
 TFX_RESIDENT=0 prof cfg1_pertick_kt --kernel-trace --stats -- --config cfg1
+}
 cd $R
 # (cfg0 / cfg1: k_res runs the whole timed region as ONE launch of 2 ms per 200 ticks: timed over 2000)
 for cfg in cfg2 cfg1 cfg0 cfg4; do

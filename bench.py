@@ -105,7 +105,7 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
                       % (envs, ticks, name, updates, dt, threads, k, dt1)}
 
 
-def load_pmc_traffic(name, kernel):
+def load_pmc_traffic(name, kernel, field="hbm_bytes_per_tick"):
     """HBM bytes per tick of the kernel that moves the cars, from the committed rocprofv3 PMC summary
     (profiles/pmc_<cfg>.json, tools/pmc_summary.py) - only if it was taken for this workload, this
     kernel AND these kernel sources (the summary carries a hash of csrc/); otherwise null."""
@@ -117,7 +117,7 @@ def load_pmc_traffic(name, kernel):
             d = json.load(f)
         if d.get("kernel") != kernel or d.get("csrc_hash") != csrc_hash():
             return None
-        return d.get("hbm_bytes_per_tick")
+        return d.get(field)
     except (OSError, ValueError, ImportError):
         return None
 
@@ -313,6 +313,10 @@ def main():
             kernel = "k_move_tt"
         traffic = load_pmc_traffic(a.config, kernel) if E == c["envs"] else None      # HBM bytes per TICK
         tpl = ((GATHER_EVERY if gather is not None else K) if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)
+        if traffic and kernel == "k_res":
+            # k_res touches HBM at the start and at the end of a launch only: the bytes per LAUNCH are what the
+            # PMC pass measured (at its own ticks per launch), whatever the number of ticks of this run's launches
+            traffic = traffic * load_pmc_traffic(a.config, kernel, "ticks_per_launch") / tpl
         out = {
             "metric": "vehicle_updates_per_sec",
             "value": total_updates / dt_max,

@@ -307,7 +307,7 @@ def main():
         achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
         kernel = eng.step_kernel()
         # two-tick passes (k_move_tt + k_edge, csrc/tfx_move_tt.hpp) took the cars through most of the timed ticks
-        # (a call ends on one or two one-tick launches, which is what step_kernel() names)
+        # (a call of an odd number of ticks ends on a one-tick launch)
         pair_ticks = eng.pair_ticks() - pair_ticks0
         if 2 * pair_ticks >= K:
             kernel = "k_move_tt"

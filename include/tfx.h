@@ -221,9 +221,10 @@ int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
 /* Ticks of this handle that ran as two-tick passes since tfx_create (transposed layout: k_move_tt takes every
  * car but the head of each road through TWO ticks per trip through HBM, k_edge finishes the second tick for
- * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp).  tfx_step uses them on its own
- * for calls of three ticks or more whose launches fill the chip, outside validate mode; results are
- * bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0 turns them off, TFX_PAIRS=2 forces them at any size. */
+ * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp).  tfx_step and tfx_agent_step use
+ * them on their own for calls of two ticks or more whose launches fill the chip (from 4 tiles of 64 roads per
+ * compute unit on), outside validate mode; results are bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0
+ * turns them off, TFX_PAIRS=2 forces them at any size. */
 int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
 /* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
  * "k_move_dma", ...), for the roofline report; "" before the first step */

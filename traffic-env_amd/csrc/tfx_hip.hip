@@ -465,11 +465,14 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   return TFX_OK;
 }
 
-// Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of three ticks or more on the transposed
-// layout whose launches fill the chip, outside validate mode (the spawn-tick plane does not travel).
-bool pairs_usable(tfx_handle h, int n_ticks) {
+// Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of two ticks or more on the transposed
+// layout whose launches fill the chip, outside validate mode (the spawn-tick plane does not travel).  A handle
+// that can use them (pairs_usable(h)) runs ALL its single ticks through k_move_tt<false>: the one-tick form that
+// reads past the rows a pair may have left empty at the top of a column.
+bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   const Dev &d = h->d;
-  if (!h->pairs || d.layout != 1 || d.w || n_ticks < 3 || h->move_variant != 0) return false;
+  // (a handle whose envs fit k_res never mixes the two: k_res loads its cars from row 0)
+  if (!h->pairs || d.layout != 1 || d.w || n_ticks < 2 || h->move_variant != 0 || h->res_epb > 0) return false;
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
@@ -542,10 +545,11 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   int rc = TFX_OK;
   {
     int t = 0;
-    if (pairs_usable(h, n_ticks)) {
+    const bool tt = pairs_usable(h);
+    if (tt) {
       // two-tick passes (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
-      // tick at a time (k_risk); the step ends on the one-tick form, which also compacts what the pairs left
-      for (; t + 2 < n_ticks && rc == TFX_OK; t += 2) {
+      // tick at a time (k_risk)
+      for (; t + 1 < n_ticks && rc == TFX_OK; t += 2) {
         rc = launch_inputs(h, st);
         if (rc == TFX_OK) rc = launch_risk(h, t, st);
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
@@ -556,15 +560,10 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
         if (rc == TFX_OK) h->pair_ticks += 2;
       }
-      for (; t < n_ticks && rc == TFX_OK; ++t) {
-        rc = launch_inputs(h, st);
-        if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t, st);
-        if (rc == TFX_OK) rc = launch_advance(h, t, st);
-      }
     }
     for (; t < n_ticks && rc == TFX_OK; ++t) {
       rc = launch_inputs(h, st);
-      if (rc == TFX_OK) rc = launch_move(h, t, st);
+      if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
       if (rc == TFX_OK) rc = launch_advance(h, t, st);
     }
   }
@@ -615,7 +614,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     if (h->grid_move == 0 && !res_usable(h, n_ticks)) {  // size the move grid outside the capture (occupancy queries)
       if (int rc = launch_move_probe(h)) return rc;
     }
-    if (!res_usable(h, n_ticks) && pairs_usable(h, n_ticks)) {
+    if (!res_usable(h, n_ticks) && pairs_usable(h)) {
       h->size_only = true;
       (void)launch_move_tt<true, true>(h, 0, nullptr);
       (void)launch_move_tt<false, true>(h, 0, nullptr);
@@ -984,10 +983,9 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     return TFX_OK;
   }
   int t = 0;
-  if (pairs_usable(h, n_ticks)) {
-    // pairs of ticks, then one or two single ticks: the first of them (k_move_tt<false>) compacts the columns
-    // the last pair left with empty head rows, so the call ends in the layout every other kernel expects
-    for (; t + 2 < n_ticks; t += 2) {
+  const bool tt = pairs_usable(h);
+  if (tt) {
+    for (; t + 1 < n_ticks; t += 2) {
       const bool timed = h->prof && h->ev_used < h->ev_ticks;
       hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
       if (int rc = launch_inputs(h, st)) return rc;
@@ -1005,28 +1003,13 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
       }
       h->pair_ticks += 2;
     }
-    {
-      const bool timed = h->prof && h->ev_used < h->ev_ticks;
-      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
-      if (int rc = launch_inputs(h, st)) return rc;
-      if (timed) HIPCHK(hipEventRecord(e[0], st));
-      if (int rc = launch_move_tt<false>(h, t, st)) return rc;
-      if (timed) HIPCHK(hipEventRecord(e[1], st));
-      if (int rc = launch_advance(h, t, st)) return rc;
-      if (timed) {
-        HIPCHK(hipEventRecord(e[2], st));
-        h->ev_weight[h->ev_used] = 1;
-        ++h->ev_used;
-      }
-      ++t;
-    }
   }
   for (; t < n_ticks; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
     if (int rc = launch_inputs(h, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[0], st));
-    if (int rc = launch_move(h, t, st)) return rc;
+    if (int rc = tt ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[1], st));
     if (int rc = launch_advance(h, t, st)) return rc;
     if (timed) {
@@ -1041,7 +1024,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
 int tfx_move_cars(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (int rc = launch_inputs(h, (hipStream_t)stream)) return rc;
-  return launch_move(h, 0, (hipStream_t)stream);
+  return pairs_usable(h) ? launch_move_tt<false>(h, 0, (hipStream_t)stream) : launch_move(h, 0, (hipStream_t)stream);
 }
 
 int tfx_advance_finished_cars(tfx_handle h, void *stream) {

@@ -51,7 +51,7 @@ __global__ void k_refresh(const Dev d) {
       d.tailx[id] = d.xv[(size_t)id * d.C + d.lastcar[id]].x;
     } else {
       const int n = ring_count(d.leading[id], d.lastcar[id], d.C);
-      d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1)].x : 0.0f;
+      d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1 + rec_hb(d.rec[id].y))].x : 0.0f;
     }
   }
 }
@@ -65,10 +65,11 @@ __global__ void k_export_ring(const Dev d, float2 *ring, float *ringw) {
     const int ld = d.leading[id];
     const int n = ring_count(ld, d.lastcar[id], d.C);
     float2 *row = ring + (size_t)id * d.C;
+    const int hb = rec_hb(d.rec[id].y);  // rows a two-tick pass left empty at the top of the column (tfx_move_tt.hpp)
     int slot = ld;
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
-      row[slot] = d.xv[tpos(d, (int)id, k)];
+      row[slot] = d.xv[tpos(d, (int)id, k + hb)];
       if (ringw && d.w) ringw[(size_t)id * d.C + slot] = d.w[tpos(d, (int)id, k)];
     }
     row[ld].x = d.leadx[id];
@@ -89,6 +90,7 @@ __global__ void k_import_ring(const Dev d, const float2 *ring, const float *ring
       if (ringw && d.w) d.w[tpos(d, (int)id, k)] = ringw[(size_t)id * d.C + slot];
     }
     d.leadx[id] = row[ld].x;
+    d.rec[id].y &= ~(3 << 28);  // the column starts at row 0 again
   }
 }
 

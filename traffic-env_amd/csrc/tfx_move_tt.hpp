@@ -15,10 +15,11 @@
 // the pops of t+1 and the road record k_advance(t+1) consumes.  Launch sequence of a pair:
 //   k_move_tt<true>(t)  k_advance(t)  [inputs of t+1]  k_edge(t+1)  k_advance(t+1)
 // and the state after it is bit for bit the state after k_move_t, k_advance, k_move_t, k_advance - except
-// that a road that popped in t+1 is not compacted: its live rows start rec_hb(rec.y) rows down.  The next
-// move kernel of the same call (another pair, or k_move_tt<false>, the one-tick form) reads from there and
-// writes the column compacted; tfx_step always ends a call on the one-tick form, so nothing outside a call
-// ever sees such a column.
+// that a road that popped in t+1 is not compacted: its live rows start rec_hb(rec.y) rows down (shifting a column
+// is uncoalesced work; reading past two rows is free).  The next move kernel - another pair, or k_move_tt<false>,
+// the one-tick form, which every handle big enough for the pairs uses for ALL its single ticks - reads from there
+// and writes the column compacted; k_advance, the serial advance, tfx_export_ring and k_refresh honour the offset,
+// tfx_import_ring and the resets clear it.
 //
 // Exactness notes: the interior cars' second step uses idm_step_fast under the same wave-wide domain test
 // as the first (both bit-identical to idm_step); k_edge uses idm_step.  The wrapped-ring quirk of the
@@ -34,7 +35,8 @@
 // of pushes is not bounded by TFX_KP).  "Can pop" is a bound, not the IDM result: a car moves at most
 // rate*v + a*rate^2/2 per tick because the acceleration never exceeds a.  Risky envs take both ticks of the pair
 // one at a time (the pass treats their tiles as the one-tick form, k_edge skips them, a one-tick launch
-// restricted to them follows); every other env provably has no overflow in tick t.
+// restricted to them follows); every other env provably has no overflow in tick t.  (An env that overflows in the
+// second tick simply stands still with its row offsets, like any other column between two launches.)
 #pragma once
 #include <type_traits>
 
@@ -69,17 +71,6 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
     const int e = valid ? e_slot : 0;
     const int id = env * d.R + e;
     const bool run = valid && !(AGENT && env_frozen(d, env, tick));
-    if (AGENT && !TWO && valid && !run) {
-      // an env that overflowed in the SECOND tick of a pair stands still from then on, its columns as k_edge
-      // left them: the one-tick form that ends the step moves them up so that nothing outside the step sees them
-      const int fb = rec_hb(d.rec[id].y);
-      if (fb > 0) {
-        float2 *fc = d.xv + ((size_t)tile * d.trows) * 64 + lane;
-        const int fn = ring_count(d.leading[id], d.lastcar[id], C);
-        for (int q = 0; q < fn; ++q) fc[(size_t)q * 64] = fc[(size_t)(q + fb) * 64];
-        d.rec[id].y &= ~(3 << 28);
-      }
-    }
     const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
     const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
     const int n_old = run ? p.n_old : 0;
@@ -224,7 +215,7 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
       if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
-      if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only; every call ends on the one-tick form)
+      if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
       my_updates += (unsigned long long)n_tot;
     }
   }
@@ -369,6 +360,7 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
     d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
                           __float_as_int(tail_x), n_tot);
     if (far || unc) d.env_flag[env] = tick + 1;
+    d.leadx[id] = p.xL;
     my_updates += (unsigned long long)n_tot;
   }
 

@@ -359,6 +359,10 @@ def main():
                          "per_tick": {"algorithmic_bytes": move_bytes, "launch_ms": move_ms, "traffic": traffic,
                                       "k_advance_ms": adv_ms},
                          "ticks_in_two_tick_passes": pair_ticks,
+                         "note": ("k_move_tt takes every car but the road heads through TWO ticks per trip through HBM: "
+                                  "its HBM traffic (`traffic`, PMC) is about half the algorithmic bytes, so `frac`, which "
+                                  "is defined on the algorithmic bytes, can exceed 1; the launch is bound by vector-ALU "
+                                  "issue (DESIGN.md 4, 5)") if kernel == "k_move_tt" else None,
                          "ticks_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,
                          "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -344,7 +344,7 @@ def main():
             # per-launch figures are the per-tick ones times `ticks_per_launch` (`per_tick` keeps the latter).
             # k_move_tt takes every car but the heads through TWO ticks per trip through HBM, so its HBM traffic is
             # about half the algorithmic bytes and `frac`, defined on the algorithmic bytes, exceeds 1: the
-            # launch is bound by vector-ALU issue, not by the 8 TB/s; `k_advance_ms` then also
+            # launch is co-limited by its stream (half the bytes) and vector-ALU issue; `k_advance_ms` then also
             # holds k_edge, the second tick of the road heads.
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -361,8 +361,8 @@ def main():
                          "ticks_in_two_tick_passes": pair_ticks,
                          "note": ("k_move_tt takes every car but the road heads through TWO ticks per trip through HBM: "
                                   "its HBM traffic (`traffic`, PMC) is about half the algorithmic bytes, so `frac`, which "
-                                  "is defined on the algorithmic bytes, can exceed 1; the launch is bound by vector-ALU "
-                                  "issue (DESIGN.md 4, 5)") if kernel == "k_move_tt" else None,
+                                  "is defined on the algorithmic bytes, can exceed 1; the launch is co-limited by that stream and by "
+                                  "vector-ALU issue (DESIGN.md 4, 5)") if kernel == "k_move_tt" else None,
                          "ticks_timed": prof["ticks"], "k_advance_ms": adv_ms,
                          "tick_algorithmic_bytes": tick_bytes,
                          "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS

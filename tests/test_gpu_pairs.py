@@ -157,6 +157,7 @@ def test_pairs_full_rings_pop_and_receive_in_the_second_tick(C):
     E, m, n, length = 6, 4, 4, 250.0
     eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=1.0)
     orc = oracle_like(eng)
+    left_in_second = 0
     for trial, T in enumerate([3, 4, 3, 6, 5]):
         x = np.zeros((E, eng.R, C), np.float32)
         v = np.zeros((E, eng.R, C), np.float32)
@@ -186,8 +187,10 @@ def test_pairs_full_rings_pop_and_receive_in_the_second_tick(C):
         eng.step(T)
         for t in range(T):
             orc.step(acts[t], roads[t])
+            if t % 2 == 1 and t < paired(T):                     # second tick of a pair
+                left_in_second += int(orc.obs[:, :eng.r].sum())
         assert_same_state(eng, orc, "C=%d trial %d (%d ticks)" % (C, trial, T))
-    assert eng.pair_ticks() > 0
+    assert eng.pair_ticks() > 0 and left_in_second > 0
 
 
 @pytest.mark.parametrize("m,n,C,length", [(2, 2, 10, 60.0), (4, 4, 20, 250.0), (3, 2, 34, 200.0), (2, 2, 130, 800.0)])

@@ -269,3 +269,53 @@ def test_columns_left_by_a_pair_between_calls():
         assert_engines_equal(a, c)
     both(lambda e: e.step(3))
     assert a.pair_ticks() >= 4 + 2 + 6 + 2 + 8 + 2 and c.pair_ticks() == 0
+
+
+def test_second_tick_pops_more_than_the_outbox_holds():
+    """Unsorted columns: a head just short of the road end with cars BEYOND the end queued behind it (the pop prefix
+    of :123 stops at the head, so they stay).  In the second tick of a pair the head leaves and takes the whole run
+    with it: more pops than the outbox holds - k_edge leaves the road uncompacted, its env takes the serial
+    advance, which meets the row offsets and full columns of the env's other roads."""
+    rng = np.random.RandomState(4711)
+    E, m, n, C, length = 8, 3, 3, 20, 250.0
+    eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    orc = oracle_like(eng)
+    big = 0
+    for trial, T in enumerate([2, 4, 3, 6]):
+        x = np.zeros((E, eng.R, C), np.float32)
+        v = np.zeros((E, eng.R, C), np.float32)
+        w = np.zeros((E, eng.R, C), np.float32)
+        leading = rng.randint(1, C, size=(E, eng.R)).astype(np.int32)
+        lastcar = leading.copy()
+        for k in range(E):
+            for e in range(eng.R):
+                kind = rng.randint(3)
+                cnt = C - 2 if kind == 0 else int(rng.randint(3, C - 2))
+                s = int(leading[k, e])
+                for j in range(cnt):
+                    s = s + 1 if s + 1 < C else 1
+                    if kind == 1 and j == 0:
+                        x[k, e, s], v[k, e, s] = length - 3.0, 4.0          # leaves in the second tick
+                    elif kind == 1 and j <= 4:
+                        x[k, e, s], v[k, e, s] = length + 10.0 * j, 0.0     # already beyond the end, behind the head
+                    else:
+                        x[k, e, s] = length - 12.0 - 5.5 * j
+                        v[k, e, s] = rng.uniform(0.0, 6.0)
+                lastcar[k, e] = s
+                x[k, e, leading[k, e]] = np.inf
+        phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        elapsed = rng.randint(6, 12, size=(E, eng.I)).astype(np.int32)
+        load_both(eng, orc, x, v, w, leading, lastcar, phase, elapsed)
+        eng.set_tick(10)
+        orc.steps[:] = 10
+        acts = np.repeat(phase[None], T, 0)
+        roads = [[[] for _ in range(E)] for _ in range(T)]
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+        eng.step(T)
+        for t in range(T):
+            orc.step(acts[t], roads[t])
+            if t == 1:
+                big = max(big, int(orc.obs[:, :eng.r].max()))
+        assert_same_state(eng, orc, "trial %d (%d ticks)" % (trial, T))
+    assert big > 2 and eng.pair_ticks() > 0

@@ -99,7 +99,10 @@ typedef struct tfx_config {
                             the k-th car behind the fake leader of the road in storage slot (64*tile + j)
                             at T[tile][k][j] (with planes = 3, w is T[tile][k][64] likewise);
                             tfx_xv_pairs gives the size, tfx_export_ring / tfx_import_ring convert to
-                            and from the ring layout */
+                            and from the ring layout.  Between calls a column may start one or two rows
+                            down (the handle remembers where: two-tick passes, tfx_pair_ticks), so T is
+                            meaningful only together with its handle - snapshot, restore or edit the cars
+                            through tfx_export_ring / tfx_import_ring, never through T itself */
 } tfx_config;
 
 typedef struct tfx_buffers {

@@ -77,6 +77,42 @@ def test_cfg2_full_size_properties(layout):
             assert all(a >= b for a, b in zip(order, order[1:])), (k, e)
 
 
+def test_cfg2_full_size_two_tick_passes_vs_oracle():
+    """The headline launch as the benchmark runs it: multi-tick calls, i.e. two-tick passes (k_move_tt + k_edge) over
+    all 4096 envs.  Sampled envs equal the oracle bit for bit after calls of even and odd lengths; an env stepped
+    alone in a tiny batch (tick-by-tick kernels: too few tiles for the pairs) has the same trajectory."""
+    c = wl.CONFIGS["cfg2"]
+    eng = wl.setup_engine("cfg2")
+    C = eng.C
+    sample = [0, 7, 1023, 2048, 4095]
+    orcs = [oracle_for(eng, c, 1, k) for k in sample]
+    small = wl.setup_engine("cfg2", envs=3, env_id_offset=2047)
+    t = 0
+    for chunk in [2, 10, 5, 8, 1, 6]:
+        eng.step(chunk)
+        small.step(chunk)
+        for _ in range(chunk):
+            for (orc, ids) in orcs:
+                step_oracle(orc, ids, eng, t, threads=1)
+            t += 1
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        for (orc, ids), k in zip(orcs, sample):
+            assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (t, k)
+            assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]), (t, k)
+            assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (t, k)
+    assert eng.pair_ticks() == 2 + 10 + 4 + 8 + 6 and small.pair_ticks() == 0
+    for (orc, ids), k in zip(orcs, sample):
+        live = live_mask(ld[k], lc[k], C)
+        xk, vk = eng.x[k].cpu().numpy(), eng.v[k].cpu().numpy()
+        assert np.array_equal(xk[live].view(np.int32), orc.x[0][live].view(np.int32)), k
+        assert np.array_equal(vk[live].view(np.int32), orc.v[0][live].view(np.int32)), k
+    assert torch.equal(small.leading, eng.leading[2047:2050]) and torch.equal(small.obs, eng.obs[2047:2050])
+    lds, lcs = small.leading.cpu().numpy(), small.lastcar.cpu().numpy()
+    for j in range(3):
+        live = live_mask(lds[j], lcs[j], C)
+        assert np.array_equal(small.x[j].cpu().numpy()[live].view(np.int32), eng.x[2047 + j].cpu().numpy()[live].view(np.int32))
+
+
 @pytest.mark.parametrize("layout", ["ring", "transposed"])
 def test_cfg2_determinism_two_runs(layout):
     a = wl.setup_engine("cfg2", envs=512, layout=layout)

@@ -319,3 +319,46 @@ def test_second_tick_pops_more_than_the_outbox_holds():
                 big = max(big, int(orc.obs[:, :eng.r].max()))
         assert_same_state(eng, orc, "trial %d (%d ticks)" % (trial, T))
     assert big > 2 and eng.pair_ticks() > 0
+
+
+def test_stale_risk_stamps_after_the_clock_is_set_back():
+    """k_risk stamps risky envs with the tick number.  Set the clock back (reset, set_tick) and an old stamp can match
+    a later pair in which the env is NOT risky: it must then be honoured all the way (one-tick form in the pass,
+    skipped by k_edge, moved by the restricted launch - which exits early only if NO tile was treated as risky)."""
+    rng = np.random.RandomState(777)
+    E = 12
+    cfg = dict(m=3, n=3, length=200.0, capacity=20, rate=0.5)
+    a = pairs_engine(E, **cfg)
+    c = pertick_engine(E, **cfg)
+    phase = rng.randint(2, size=(E, a.I)).astype(np.int32)
+
+    def wild(envs, tick):
+        """pathological cars in `envs` (risky for sure), nothing anywhere else; one decision of two ticks"""
+        x, v, w, leading, lastcar = random_state(rng, E, a.R, 20, 200.0, crowd=0.9, beyond=1.6, sorted_x=False)
+        keep = np.zeros(E, bool)
+        keep[envs] = True
+        x[~keep], v[~keep] = 0.0, 0.0
+        leading[~keep], lastcar[~keep] = 1, 1
+        for eng in (a, c):
+            eng.reset(phase)
+            eng.load_state(x, v, leading, lastcar)
+            eng.set_tick(tick)
+            eng.set_spawns(period=3)
+            eng.set_actions(phase)
+            eng.agent_step(2, remi=True)
+        assert_engines_equal(a, c)
+    wild(slice(0, 6), 40)                        # envs 0-5 stamped for the pair (40, 41)
+    wild(slice(6, 12), 50)                       # envs 6-11 for (50, 51): "somebody is risky" now says 51
+    xb, vb, lb, cb = wl.prefill_one_env(3, 3, 200.0, 20, 6, 12.0)
+    for eng in (a, c):
+        eng.reset(phase)
+        eng.load_state(np.repeat(xb[None], E, 0), np.repeat(vb[None], E, 0), np.repeat(lb[None], E, 0), np.repeat(cb[None], E, 0))
+        eng.set_tick(40)                         # nobody is risky now, but envs 0-5 still carry the stamp of tick 40
+        eng.set_spawns(period=3)
+        eng.set_actions(phase)
+    ra = [t.clone() for t in a.agent_step(2, remi=True)]
+    rc = [t.clone() for t in c.agent_step(2, remi=True)]
+    for u, w_ in zip(ra, rc):
+        assert torch.equal(u, w_)
+    assert_engines_equal(a, c)
+    assert a.tick == c.tick == 42

@@ -63,6 +63,7 @@ struct Dev {
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
   int *env_flag;  // == tick+1 when the env must take the serial advance this tick
   int *env_risk;  // == tick+1 when the env takes the pair of ticks starting at `tick` one tick at a time (k_risk)
+  int *risk_any;  // == tick+1 when k_risk marked any env for the pair starting at `tick`
   unsigned long long *veh;
   int *tickA, *tickB;
   // per-tick inputs

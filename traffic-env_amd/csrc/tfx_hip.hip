@@ -764,6 +764,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
   d.agent_first = (const int *)(base + o_misc + 48);
+  d.risk_any = (int *)(base + o_misc + 56);
   // reciprocal division is used only if it is exact for this handle's constants on the whole
   // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
   d.fastdiv = 0;

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
 
+  if (AGENT && only_risky && *d.risk_any != tick) return;  // (k_edge has moved every env and the clock)
+
   unsigned long long my_updates = 0;
 
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
@@ -66,6 +68,9 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
     if (AGENT && only_risky && d.env_risk[env] != tick) continue;
     // this tile goes through two ticks (wave-uniform)
     const bool two = TWO && !(AGENT && d.env_risk[env] == tick + 1);
+    // (a stamp left by an earlier run at the same tick number - the clock can be set back - is honoured all the
+    // way: this pass takes the tile one tick at a time, k_edge skips it, and the restricted launch must come)
+    if (AGENT && TWO && !two && lane == 0) *d.risk_any = tick + 1;
     const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
     const bool valid = e_slot >= 0;
     const int e = valid ? e_slot : 0;
@@ -263,7 +268,10 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
       const int idn = env * d.R + nx;
       if (ring_count(d.leading[idn], d.lastcar[idn], C) + pops > C - 2) risky = true;
     }
-    if (risky) d.env_risk[env] = tick + 1;
+    if (risky) {
+      d.env_risk[env] = tick + 1;
+      *d.risk_any = tick + 1;
+    }
   }
 }
 

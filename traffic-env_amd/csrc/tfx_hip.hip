@@ -67,6 +67,7 @@ struct tfx_handle_s {
   int grid_move = 0;
   int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
+  int grid_adv = 0;
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
@@ -458,9 +459,23 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
 
 int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   const Dev &d = h->d;
-  const long items = (long)d.E * (d.I + d.R - d.r);
-  if (d.layout == 1) hipLaunchKernelGGL(k_advance<true>, dim3(grid_for(items, h->n_cu)), dim3(256), 0, st, d, tidx);
-  else hipLaunchKernelGGL(k_advance<false>, dim3(grid_for(items, h->n_cu)), dim3(256), 0, st, d, tidx);
+  if (h->grid_adv == 0) {
+    // no more blocks than are resident at once (k_advance<true> holds 5 per CU): with 8 per CU launched the
+    // last three of every CU start when the first five have finished their whole grid-stride loop
+    const long items = (long)d.E * (d.I + d.R - d.r);
+    int per_cu = 0;
+    const hipError_t qe = d.layout == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_advance<true>, 256, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_advance<false>, 256, 0);
+    if (qe != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    if (const char *pc = getenv("TFX_ADVANCE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+    long g = (items + 255) / 256;
+    if (g > (long)h->n_cu * per_cu) g = (long)h->n_cu * per_cu;
+    h->grid_adv = (int)(g < 1 ? 1 : g);
+  }
+  if (h->size_only) return TFX_OK;
+  if (d.layout == 1) hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+  else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -613,6 +628,11 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     if (!h->ag_stream) HIPCHK(hipStreamCreateWithFlags(&h->ag_stream, hipStreamNonBlocking));
     if (h->grid_move == 0 && !res_usable(h, n_ticks)) {  // size the move grid outside the capture (occupancy queries)
       if (int rc = launch_move_probe(h)) return rc;
+    }
+    if (!res_usable(h, n_ticks) && h->grid_adv == 0) {
+      h->size_only = true;
+      (void)launch_advance(h, 0, nullptr);
+      h->size_only = false;
     }
     if (!res_usable(h, n_ticks) && pairs_usable(h)) {
       h->size_only = true;

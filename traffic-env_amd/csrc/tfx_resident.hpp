@@ -421,8 +421,10 @@ void k_res(const Dev d, const ResArgs a) {
           if (act) RG(csl[u], t) = make_float2(xn[u], vn[u]);
           const bool pop = open && act && (xn[u] > d.length);  // the while loop of :123
           open = act ? pop : open;  // (rows past the lane's share leave it as it is: the halves combine on it)
-          kpop += pop ? 1 : 0;
-          far = far || (pop && ((xn[u] - d.length) > d.length));
+          if (pop) {  // (rare: kept out of the common path - cfg1 x 1024: 8.67 -> 8.45 us per tick)
+            ++kpop;
+            far = far || ((xn[u] - d.length) > d.length);
+          }
           const float wq = (k >= kq) ? xn[u] : vn[u];
           n_wait += (act && wq < d.thresh) ? 1 : 0;
           n_det += (act && xn[u] > d.near_end) ? 1 : 0;

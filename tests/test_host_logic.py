@@ -279,3 +279,22 @@ def test_pmc_traffic_is_reported_only_for_the_profiled_sources(tmp_path, monkeyp
     for cfg in ("cfg1", "cfg2", "cfg4"):
         d = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg)))
         assert len(d["csrc_hash"]) == 16 and d["kernel"] in pmc_summary.MOVERS and d["hbm_bytes_per_tick"] > 0
+
+
+def test_pmc_summary_tells_the_move_kernels_apart():
+    """tools/pmc_summary.py keys its tables by a short kernel name: the two-tick pass, its one-tick form and the
+    older movers must not fold into each other (k_move_tt would otherwise be read as k_move_t + "t")."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary as ps
+    assert ps.short("void tfx::k_move_tt<true, false>(tfx::Dev, int, int)") == "k_move_tt"
+    assert ps.short("void tfx::k_move_tt<false, false>(tfx::Dev, int, int)") == "k_move_tt1"
+    assert ps.short("void tfx::k_move_t<4, 3, false>(tfx::Dev, int)") == "k_move_t"
+    assert ps.short("void tfx::k_move_t2<4, 3>(tfx::Dev, int)") == "k_move_t2"
+    assert ps.short("void tfx::k_move_ts<16, false>(tfx::Dev, int)") == "k_move_ts"
+    assert ps.short("void tfx::k_edge<false>(tfx::Dev, int)") == "k_edge"
+    assert ps.short("void tfx::k_advance<true>(tfx::Dev, int)") == "k_advance"
+    assert ps.short("void tfx::k_res<2, false>(tfx::Dev, tfx::ResArgs)") == "k_res"
+    assert ps.short("void at::native::vectorized_elementwise_kernel<4>(int)") is None

@@ -37,7 +37,7 @@ SCENARIOS = {}
 def scen(name, **kw):
     d = dict(m=2, n=2, L=250.0, C=20, seed=0, T=300, poisson=True, rate=0.5, lcps=0.12,
              entry='all', learn_switch=False, mode='train', actions='random10',
-             remi_every=10, state_every=1, mid=False)
+             remi_every=10, state_every=1, state_next=False, mid=False)
     d.update(kw)
     SCENARIOS[name] = d
 
@@ -56,6 +56,13 @@ scen("g3x3_default", m=3, n=3, seed=0, T=400)
 scen("g3x2_rect", m=3, n=2, seed=5, T=240, C=16, lcps=0.2)
 scen("g4x4_cfg1", m=4, n=4, L=200.0, C=34, seed=0, T=300, lcps=0.3, state_every=10)
 scen("g16x16_cfg2_ints", m=16, n=16, L=400.0, C=66, seed=0, T=150, lcps=0.25, state_every=0)
+# CAPACITY = 130 (BASELINE config 5's 128-car roads, traffic_env.py:46-47,202-212 with rings longer than one
+# wavefront): one car per entry road every two ticks - more than a signalised road discharges - so all 32 entry roads
+# grow past 64 cars (from tick ~130), reach 128, overflow (from tick 206) and wrap their rings (14 000 wrapped
+# road-ticks) while they keep handing cars over; car states of ticks 20 j and 20 j + 1 (teacher-forced floats)
+scen("g8x8_c130", m=8, n=8, L=800.0, C=130, seed=6, T=700, poisson=False, lcps=1.0, state_every=20, state_next=True)
+# config 5 itself for the first 130 ticks (integers only): 64x64, Poisson arrivals at the default rate
+scen("g64x64_c130_ints", m=64, n=64, L=800.0, C=130, seed=0, T=130, state_every=0)
 
 
 def run(name, sc, mods):
@@ -155,7 +162,7 @@ def run(name, sc, mods):
             waiting[k] = env.waiting
             passed_dst[k] = env.passed_dst
             leader_x[k] = env.state[np.arange(R), xi, env.leading]
-            if se and k % se == 0:
+            if se and (k % se == 0 or (sc.get("state_next") and k % se == 1)):
                 x, v, w = live_planes(env.state, env.leading, env.lastcar, C, (xi, vi, wi))
                 st_ticks.append(k)
                 st_x.append(x)

@@ -276,3 +276,66 @@ def test_cfg4_sixteen_envs_properties():
     # agree; the envs still differ car by car - each has its own arrival stream)
     xv = eng.xv
     assert not torch.equal(xv[0], xv[1])
+
+
+def test_cfg1_full_batch_default_resident_packing_vs_oracle(monkeypatch):
+    """BASELINE config 2 as the benchmark runs it: 1024 envs of 4x4 x 32-car roads through k_res with the DEFAULT
+    env-per-workgroup packing (no TFX_RES_EPB / TFX_RES_LPR / TFX_RESIDENT override), 60 ticks in uneven
+    tfx_step(n) calls and then two fused 10-tick agent decisions (Repeater + Remi, traffic_test.py:27-64); sampled
+    envs equal the oracle bit for bit after every call - ring indices, obs, rewards, waiting, every live car."""
+    for var in ("TFX_RES_EPB", "TFX_RES_LPR", "TFX_RESIDENT", "TFX_RES_MIN_TICKS", "TFX_PAIRS", "TFX_LAYOUT",
+                "TFX_MOVE_VARIANT"):
+        monkeypatch.delenv(var, raising=False)
+    c = wl.CONFIGS["cfg1"]
+    eng = wl.setup_engine("cfg1")
+    E, C, r, I = eng.E, eng.C, eng.r, eng.I
+    assert (E, eng.R, C) == (1024, 80, 34) and eng.fused_ticks()[1]
+    sample = [0, 1, 255, 256, 511, 777, 1023]
+    orcs = [oracle_for(eng, c, 1, k) for k in sample]
+
+    def check(tag):
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        ob, rw, wt = eng.obs.cpu().numpy(), eng.rewards.cpu().numpy(), eng.waiting.cpu().numpy()
+        xs, vs = eng.x.cpu().numpy(), eng.v.cpu().numpy()
+        for (orc, ids), k in zip(orcs, sample):
+            assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (tag, k)
+            assert np.array_equal(ob[k], orc.obs[0]) and np.array_equal(wt[k], orc.waiting[0]), (tag, k)
+            assert np.array_equal(rw[k], orc.rewards[0]), (tag, k)
+            live = live_mask(ld[k], lc[k], C)
+            assert np.array_equal(xs[k][live].view(np.int32), orc.x[0][live].view(np.int32)), (tag, k)
+            assert np.array_equal(vs[k][live].view(np.int32), orc.v[0][live].view(np.int32)), (tag, k)
+
+    t = 0
+    for chunk in [1, 7, 10, 3, 9, 13, 17]:
+        eng.step(chunk)
+        assert eng.step_kernel() == "k_res"
+        for _ in range(chunk):
+            for (orc, ids) in orcs:
+                step_oracle(orc, ids, eng, t, threads=1)
+            t += 1
+        check(t)
+    assert t == 60 and eng.fused_ticks()[0] == 60
+    # two fused decisions: obs accumulation, remi reward and `if done: break` per env (traffic_test.py:37-64)
+    for dec in range(2):
+        aobs, arew, adone = eng.agent_step(10, remi=True)
+        aobs, arew, adone = aobs.cpu().numpy(), arew.cpu().numpy(), adone.cpu().numpy()
+        for (orc, ids), k in zip(orcs, sample):
+            total_obs, done = np.zeros(2 * r + I, np.float32), False
+            for j in range(10):
+                obs, rew, d = step_oracle(orc, ids, eng, t + j, threads=1)
+                obs, done = obs[0], bool(d[0])
+                total_obs[:r] += obs[:r]
+                total_obs[r:2 * r] = obs[r:2 * r]
+                total_obs[-I:] = obs[-I:] / 100 * (2 * obs[-2 * I:-I] - 1)
+                if done:
+                    break
+            assert not done        # (the benchmark's traffic does not overflow this early: the clocks stay aligned)
+            assert np.array_equal(aobs[k], total_obs), (dec, k)
+            assert np.array_equal(arew[k], orc.remi_reward()[0]), (dec, k)
+            assert adone[k] == 0, (dec, k)
+        t += 10
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        for (orc, ids), k in zip(orcs, sample):
+            assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (dec, k)
+            assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (dec, k)
+    assert eng.step_kernel() == "k_res"

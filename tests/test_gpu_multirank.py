@@ -1,7 +1,7 @@
 """The N > 1 path on ONE GPU: two ranks share device 0 and talk over gloo (the rehearsal mode of
 bench.py) - the env-sharded step with global env ids, the packed (obs | reward | done) gather to rank 0
-and the self-launching benchmark.  RCCL itself needs more than one GPU and is exercised by the
-driver's multi-GPU runs only."""
+and the self-launching benchmark.  RCCL itself needs more than one GPU: test_two_gpus_rccl_gather runs
+the real `nccl` RolloutGather as soon as two devices are visible and is skipped on a one-GPU box."""
 import json
 import os
 import socket
@@ -78,3 +78,69 @@ def test_bench_launches_two_ranks_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert "gather" in out["config"]["parallelism"] and out["config"]["envs_per_gpu"] == 256
+
+
+def test_snapshot_is_not_torn_by_the_ticks_that_follow():
+    """start() returns at once and the caller steps on: the snapshot must hold the tick it was taken at, not
+    whatever the following ticks wrote into obs / rewards / done while the copy was in flight."""
+    from gym_traffic import workload as wl
+    from gym_traffic.distributed import RolloutGather
+    eng = wl.setup_engine("cfg2", envs=512)
+    gather = RolloutGather(eng.E, eng.obs_len, eng.I, eng.device)
+    for rep in range(6):
+        eng.step(10)
+        want = (eng.obs.clone(), eng.rewards.clone(), eng.done.clone())
+        gather.start(eng.obs, eng.rewards, eng.done)
+        eng.step(7)                       # overwrites all three buffers right behind the snapshot
+        got = gather.result()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), rep
+    assert gather.collectives == 0        # a single rank gathers nothing
+
+
+def _rccl_rank(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    try:
+        from gym_traffic import workload as wl
+        from gym_traffic.distributed import shard_range, RolloutGather
+        lo, hi = shard_range(301, rank, world)
+        eng = wl.setup_engine("cfg2", device=device, envs=hi - lo, env_id_offset=lo)
+        sizes = [b - a for a, b in (shard_range(301, r, world) for r in range(world))]
+        gather = RolloutGather(hi - lo, eng.obs_len, eng.I, device, counts=sizes)
+        assert gather.stage_dev == device                      # RCCL: the snapshots stay on the device
+        for _ in range(4):
+            eng.step(10)
+            gather.start(eng.obs, eng.rewards, eng.done)
+        eng.step(5)                                                # the gather of tick 40 overlaps these ticks
+        res = gather.result()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "gathered.npz"), obs=res[0].cpu().numpy(), rew=res[1].cpu().numpy(),
+                     done=res[2].cpu().numpy(), collectives=gather.collectives)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (this box has one)")
+def test_two_gpus_rccl_gather_equals_one_process(tmp_path):
+    """cfg3's code path for real: one rank per GPU, backend nccl (= RCCL over xGMI), uneven shards (151 + 150 envs,
+    so the padding of the smaller shard is exercised), four snapshots with ticks running behind each."""
+    from gym_traffic import workload as wl
+    world = 2
+    mp.spawn(_rccl_rank, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
+    ref = wl.setup_engine("cfg2", envs=301)
+    for _ in range(4):
+        ref.step(10)
+    assert int(z["collectives"]) == 4
+    assert np.array_equal(z["obs"], ref.obs.cpu().numpy())
+    assert np.array_equal(z["rew"], ref.rewards.cpu().numpy())
+    assert np.array_equal(z["done"], ref.done.cpu().numpy())

@@ -69,27 +69,33 @@ class RolloutGather(object):
 
     def start(self, obs, rewards, done):
         """Snapshot the three tensors and start gathering them to `dst`; returns immediately.  Only
-        the gather that last used this snapshot's buffer (two starts ago) is waited for."""
+        the gather that last used this snapshot's buffer (two starts ago) is waited for.
+
+        The snapshot copy runs on the CALLER's stream, in order with the ticks before and after it: the
+        kernels of the next ticks cannot overwrite obs / rewards / done under a copy that is still in
+        flight (it is ~50 MB at cfg3, tens of microseconds).  Only the gather goes to the side stream, which
+        waits for the copy; the caller's stream never waits for the gather of this snapshot."""
         k = self.started % self.DEPTH
         self.started += 1
         snap = self.snap[k]
         n, L, I = self.n, self.L, self.I
-        if self.side is not None:
+        self._wait_slot(k)            # (RCCL: orders the caller's stream after that gather; gloo: blocks)
+        snap[:n * L].view(n, L).copy_(obs, non_blocking=True)
+        snap[self.o_rew:self.o_rew + n * I].view(torch.float32).view(n, I).copy_(rewards, non_blocking=True)
+        snap[self.o_done:self.o_done + n].copy_(done, non_blocking=True)       # u8 -> i32
+        if self.side is None:
+            ctx = _Null()
+        elif self.stage_dev.type == "cpu":
+            torch.cuda.current_stream(self.device).synchronize()    # host copies must have landed before gloo reads them
+            ctx = _Null()
+        else:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             ctx = torch.cuda.stream(self.side)
-        else:
-            ctx = _Null()
-        with ctx:
-            self._wait_slot(k)        # (RCCL: orders the side stream after that gather; gloo: blocks)
-            snap[:n * L].view(n, L).copy_(obs, non_blocking=True)
-            snap[self.o_rew:self.o_rew + n * I].view(torch.float32).view(n, I).copy_(rewards, non_blocking=True)
-            snap[self.o_done:self.o_done + n].copy_(done, non_blocking=True)       # u8 -> i32
-            if self.stage_dev.type == "cpu" and self.side is not None:
-                self.side.synchronize()            # host copies must have landed before gloo reads them
-            if self.world > 1:
+        if self.world > 1:
+            with ctx:
                 self.pending[k] = dist.gather(snap, self.recv[k] if self.rank == self.dst else None,
                                               dst=self.dst, group=self.group, async_op=True)
-                self.collectives += 1
+            self.collectives += 1
 
     def wait(self):
         """Block the host until every started gather has landed (no-op if none)."""

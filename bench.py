@@ -122,6 +122,79 @@ def load_pmc_traffic(name, kernel, field="hbm_bytes_per_tick"):
         return None
 
 
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 vector instructions per ns the chip can issue: 256 CUs x 4 SIMDs at
+#                                      2.4 GHz, one per 2 cycles per SIMD with >= 2 wavefronts resident (the guide's
+#                                      `v_fma_f32 (wave64) 2 cyc`) = 1228.8 G wave-instructions / s
+
+
+def roofline(a, c, eng, E, prof, prof_updates, gathering, dt, updates):
+    """The dominant kernel against the roofline that bounds it.
+
+    HBM-bound kernels (the streaming move kernels): ALGORITHMIC bytes of one launch / its mean duration / 8 TB/s.
+    One launch that takes the cars through T ticks (k_move_tt: T = 2) reads and writes every live car ONCE -
+    16 B per car - and the per-road words once per tick - 48 B per road and tick (SURVEY.md 8d's figures):
+        bytes per launch = 16 N_live + T 48 E R.
+    (SURVEY's per-tick model, 16 B per vehicle-UPDATE, would count the cars T times; a T-tick pass is the
+    point of moving them once, so that figure is kept as `per_tick_model` and is not a fraction of anything.)
+    `traffic` is the PMC measurement of the same launch (profiles/pmc_<cfg>.json, only while the kernel sources are
+    the profiled ones); `frac` must agree with traffic / launch time / peak within a few percent.
+
+    k_res keeps the cars in LDS for all ticks of a call and touches HBM twice per call: it is bound by vector
+    instruction issue, so its roofline is wave-instructions per second against the chip's issue rate (the
+    instruction count per tick comes from the PMC pass, SQ_INSTS_VALU)."""
+    from gym_traffic import workload as wl
+    K = prof["ticks"]
+    live = prof_updates / max(1, K)                                     # mean live cars per tick (roofline pass)
+    move_ms = prof["move_ms"] / max(1, K)                               # per tick
+    rest_ms = prof["advance_ms"] / max(1, K)
+    kernel = eng.step_kernel()
+    if 2 * (eng.pair_ticks()) >= K and kernel.startswith("k_move_tt"):
+        kernel = "k_move_tt"
+    tpl = ((GATHER_EVERY if gathering else K) if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)
+    launch_ms = move_ms * tpl
+    full = E == c["envs"]
+    if kernel == "k_res":
+        insts = load_pmc_traffic(a.config, kernel, "valu_insts_per_tick") if full else None
+        ach = insts / (move_ms * 1e6) if insts and move_ms > 0 else None     # G wave-instructions / s
+        return {"bound": "valu", "kernel": kernel, "achieved": ach, "peak": VALU_PEAK_GINST,
+                "unit": "G wave64-instructions/s", "frac": ach / VALU_PEAK_GINST if ach else None,
+                "traffic": None, "valu_instructions_per_tick": insts, "launch_ms": launch_ms,
+                "ticks_per_launch": tpl, "ticks_timed": K,
+                "note": "LDS-resident multi-tick kernel: HBM is touched at the start and the end of a call only; "
+                        "the bound is vector-instruction issue (count from the PMC pass x 2 cycles per wave64 "
+                        "instruction / 1024 SIMDs / 2.4 GHz)"}
+    road_ticks = E * eng.R
+    alg = 16.0 * live + tpl * 48.0 * road_ticks
+    achieved = alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    traffic = load_pmc_traffic(a.config, kernel, "k_move_hbm_bytes_per_launch") if full else None
+    per_tick_model = tpl * (16.0 * live + 48.0 * road_ticks)
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_frac": traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and launch_ms > 0 else None,
+            "frac_of_measured_stream_peak": achieved / HBM_STREAM_GBS,
+            "algorithmic_bytes_per_launch": alg, "launch_ms": launch_ms, "ticks_per_launch": tpl,
+            "ticks_timed": K, "rest_of_tick_ms": rest_ms,
+            "per_tick_model": {"bytes_per_launch": per_tick_model,
+                               "rate_GBs": per_tick_model / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
+                               "note": "SURVEY 8d's 16 B per vehicle-UPDATE x the updates of the launch: counts the "
+                                       "cars once per tick although a T-tick pass moves them once; not a fraction "
+                                       "of the HBM peak"},
+            # the whole timed region against the same peak: SURVEY 8d's bytes of every tick / wall time
+            "timed_region": {"algorithmic_GBs": wl.algorithmic_bytes_per_tick(
+                                 updates / max(1, a.steps), road_ticks, E * eng.I) * a.steps / dt / 1e9,
+                             "note": "per-tick model bytes of all ticks / wall time of the timed region (launches of "
+                                     "two env halves overlap there)"},
+            "measured": "HIP events on the launch stream around every launch of the kernel, in a second pass over "
+                        "the same K ticks right after the timed region (no events inside the timed region; the env "
+                        "range is not split over two streams while a launch is timed)"}
+
+
+def numpy_baseline(name, budget_s=8.0):
+    """SURVEY 8d's second CPU leg: the same tick as batched NumPy array arithmetic on ONE core (oracle/numpy_env.py)."""
+    from oracle.numpy_env import time_config
+    return time_config(name, budget_s)
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -212,6 +285,7 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-numpy-baseline", action="store_true")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the N > 1 plumbing (parent launch, rendezvous, gather, relay); "
                          "runs no kernel and measures nothing")
@@ -269,23 +343,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # (the HIP events of the per-kernel timing are created BEFORE the warm-up and re-armed after it, so that
-    # no host work sits between the warm-up and the timed region: after even a millisecond of idleness
-    # the first launch runs at a lower clock, which a 2 ms k_res launch - cfg0 / cfg1 - would show in full)
-    eng.profile(a.steps)
+    # Timed region: nothing but the K ticks (no HIP events in it - round 2 recorded three per pair of ticks there).
     run(a.warmup)
-    eng.profile_read()
     eng.reset_counters()
-    pair_ticks0 = eng.pair_ticks()
+    pair_ticks0, split_ticks0 = eng.pair_ticks(), eng.split_ticks()
     fence()
     t0 = time.perf_counter()
     run(a.steps)
     fence()
     dt = time.perf_counter() - t0
-
     updates = eng.vehicle_updates()
+    pair_ticks = eng.pair_ticks() - pair_ticks0
+    split_ticks = eng.split_ticks() - split_ticks0
+
+    # Roofline pass: the SAME K ticks again, now with HIP events on the launch stream around every launch of the
+    # kernel that moves the cars (tfx_profile).  While it is timed a launch owns the chip: the handle does not
+    # split the env range over two streams in this pass (tfx_split_ticks), so the duration is the kernel's own.
+    eng.profile(a.steps)
+    eng.reset_counters()
+    fence()
+    run(a.steps)
+    fence()
     prof = eng.profile_read()
+    prof_updates = eng.vehicle_updates()
     eng.profile(0)
+
     red_dev = torch.device("cpu") if rehearsal else device
     tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     uu = torch.tensor([updates], dtype=torch.float64, device=red_dev)
@@ -296,27 +378,6 @@ def main():
 
     if rank == 0:
         K = a.steps
-        live_per_tick = updates / K                                   # rank 0's mean live cars / tick
-        move_ms = prof["move_ms"] / max(1, prof["ticks"])
-        adv_ms = prof["advance_ms"] / max(1, prof["ticks"])
-        # algorithmic bytes: 16 B per vehicle-update + 48 B per road-tick go to
-        # k_move (it reads/writes every car and the per-road words); the 32 B per
-        # intersection-tick belong to k_advance.  See DESIGN.md "Roofline accounting".
-        move_bytes = 16.0 * live_per_tick + 48.0 * E * eng.R
-        tick_bytes = wl.algorithmic_bytes_per_tick(live_per_tick, E * eng.R, E * eng.I)
-        achieved = move_bytes / (move_ms * 1e-3) / 1e9 if move_ms > 0 else 0.0
-        kernel = eng.step_kernel()
-        # two-tick passes (k_move_tt + k_edge, csrc/tfx_move_tt.hpp) took the cars through most of the timed ticks
-        # (a call of an odd number of ticks ends on a one-tick launch)
-        pair_ticks = eng.pair_ticks() - pair_ticks0
-        if 2 * pair_ticks >= K:
-            kernel = "k_move_tt"
-        traffic = load_pmc_traffic(a.config, kernel) if E == c["envs"] else None      # HBM bytes per TICK
-        tpl = ((GATHER_EVERY if gather is not None else K) if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)
-        if traffic and kernel == "k_res":
-            # k_res touches HBM at the start and at the end of a launch only: the bytes per LAUNCH are what the
-            # PMC pass measured (at its own ticks per launch), whatever the number of ticks of this run's launches
-            traffic = traffic * load_pmc_traffic(a.config, kernel, "ticks_per_launch") / tpl
         out = {
             "metric": "vehicle_updates_per_sec",
             "value": total_updates / dt_max,
@@ -339,37 +400,15 @@ def main():
                            if gather is not None else "")},
             "env_steps_per_sec": world * E * K / dt_max,
             "agent_steps_per_sec": world * E * K / dt_max / GATHER_EVERY,   # one decision = 10 ticks
-            "mean_live_cars_per_road": live_per_tick / (E * eng.R),
-            # One launch of k_res covers all the ticks of a tfx_step call, one launch of k_move_tt two: the
-            # per-launch figures are the per-tick ones times `ticks_per_launch` (`per_tick` keeps the latter).
-            # k_move_tt takes every car but the heads through TWO ticks per trip through HBM, so its HBM traffic is
-            # about half the algorithmic bytes and `frac`, defined on the algorithmic bytes, exceeds 1: the
-            # launch is co-limited by its stream (half the bytes) and vector-ALU issue; `k_advance_ms` then also
-            # holds k_edge, the second tick of the road heads.
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic * tpl if traffic else None,
-                         # the PMC bytes over the live launch time, and that rate against the part's
-                         # measured streaming ceiling (informative; `frac` above is against the 8 TB/s spec)
-                         "traffic_rate_GBs": traffic / (move_ms * 1e-3) / 1e9 if traffic and move_ms > 0 else None,
-                         "traffic_frac_of_measured_stream_peak": traffic / (move_ms * 1e-3) / 1e9 / HBM_STREAM_GBS
-                         if traffic and move_ms > 0 else None,
-                         "algorithmic_bytes_per_launch": move_bytes * tpl, "launch_ms": move_ms * tpl,
-                         "ticks_per_launch": tpl,
-                         "per_tick": {"algorithmic_bytes": move_bytes, "launch_ms": move_ms, "traffic": traffic,
-                                      "k_advance_ms": adv_ms},
-                         "ticks_in_two_tick_passes": pair_ticks,
-                         "note": ("k_move_tt takes every car but the road heads through TWO ticks per trip through HBM: "
-                                  "its HBM traffic (`traffic`, PMC) is about half the algorithmic bytes, so `frac`, which "
-                                  "is defined on the algorithmic bytes, can exceed 1; the launch is co-limited by that stream and by "
-                                  "vector-ALU issue (DESIGN.md 4, 5)") if kernel == "k_move_tt" else None,
-                         "ticks_timed": prof["ticks"], "k_advance_ms": adv_ms,
-                         "tick_algorithmic_bytes": tick_bytes,
-                         "tick_frac": tick_bytes / ((move_ms + adv_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                         if move_ms + adv_ms > 0 else 0.0},
+            "mean_live_cars_per_road": updates / K / (E * eng.R),
+            "ticks_in_two_tick_passes": pair_ticks,
+            "ticks_split_over_two_streams": split_ticks,
+            "roofline": roofline(a, c, eng, E, prof, prof_updates, gather is not None, dt_max, updates),
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config)
+            if not a.no_numpy_baseline:
+                out["cpu_baseline"]["numpy_batched_one_core"] = numpy_baseline(a.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 9
+#define TFX_ABI_VERSION 10
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
 
 enum {
@@ -229,6 +229,18 @@ int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
  * compute unit on), outside validate mode; results are bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0
  * turns them off, TFX_PAIRS=2 forces them at any size. */
 int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
+/* ... of which the rest of the pair - advance_finished_cars of the first tick (traffic_env.py:117-135), the road
+ * heads' second tick, advance_finished_cars of the second - ran as ONE launch with a workgroup per env (k_tail,
+ * csrc/tfx_tail.hpp) instead of three: tfx_step does so on its own from one env per compute unit on, unless the
+ * second tick's inputs are produced on the device in between (tfx_set_poisson, TFX_ACTION_GREEDY).  TFX_TAIL=0
+ * turns it off, TFX_TAIL=2 forces it at any batch size; results are bit-identical. */
+int tfx_tail_ticks(tfx_handle h, int64_t *ticks);
+/* Ticks of tfx_step calls that ran as two halves of the env range, the second half on a stream the handle owns
+ * (forked from and joined to the caller's stream with events, so the call keeps its stream semantics): the
+ * latency-bound per-road launch of one half then runs under the other half's pass over the cars.  Used for calls
+ * of pairs whose halves still fill the chip, never while tfx_profile is timing kernels.  TFX_SPLIT=0 turns it off,
+ * TFX_SPLIT=2 forces it at any batch size; results are bit-identical (envs share nothing, traffic_env.py:361-382). */
+int tfx_split_ticks(tfx_handle h, int64_t *ticks);
 /* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
  * "k_move_dma", ...), for the roofline report; "" before the first step */
 const char *tfx_step_kernel(tfx_handle h);

@@ -21,6 +21,8 @@ def step_path(request, monkeypatch):
     monkeypatch.setenv("TFX_RES_EPB", "3")
     # "pairs": two ticks per pass over the cars (k_move_tt + k_edge, k_risk inside agent steps), forced at test sizes
     monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
+    monkeypatch.setenv("TFX_TAIL", "2")        # (with the pairs: k_tail behind every pass, csrc/tfx_tail.hpp,
+    monkeypatch.setenv("TFX_SPLIT", "2")       #  and the env range in two halves on two streams)
     yield request.param
 
 

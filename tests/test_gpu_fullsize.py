@@ -101,6 +101,8 @@ def test_cfg2_full_size_two_tick_passes_vs_oracle():
             assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]), (t, k)
             assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (t, k)
     assert eng.pair_ticks() == 2 + 10 + 4 + 8 + 6 and small.pair_ticks() == 0
+    # ... behind every pass one k_tail launch, the batch in two halves on two streams (the defaults at this size)
+    assert eng.tail_ticks() == eng.pair_ticks() and eng.split_ticks() == 2 + 10 + 5 + 8 + 6
     for (orc, ids), k in zip(orcs, sample):
         live = live_mask(ld[k], lc[k], C)
         xk, vk = eng.x[k].cpu().numpy(), eng.v[k].cpu().numpy()

@@ -18,8 +18,21 @@ torch = pytest.importorskip("torch")
 from gym_traffic import workload as wl  # noqa: E402
 
 
+_TAIL = ["2", "0"]
+
+
+@pytest.fixture(params=["tail", "launches", "split"], autouse=True)
+def pair_tail(request):
+    """What follows a pass: k_tail - advance(t), the edge work of t+1 and advance(t+1) in one launch, a workgroup per
+    env (csrc/tfx_tail.hpp, forced at test sizes) - or the three separate launches; "split": k_tail, and tfx_step runs
+    the env range as two halves on two streams (tfx_split_ticks)."""
+    _TAIL[:] = ["0" if request.param == "launches" else "2", "2" if request.param == "split" else "0"]
+    yield request.param
+    _TAIL[:] = ["2", "0"]
+
+
 def pairs_engine(E, **cfg):
-    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2"}, E, **cfg)
+    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": _TAIL[0], "TFX_SPLIT": _TAIL[1]}, E, **cfg)
     assert eng.pair_ticks() == 0
     return eng
 
@@ -71,6 +84,8 @@ def test_pairs_random_states_vs_oracle(m, n, C, length, sorted_x):
         assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), trial
         assert_same_state(eng, orc, "trial %d (%d ticks)" % (trial, T))
     assert eng.pair_ticks() == ran and eng.step_kernel() == "k_move_tt"
+    assert eng.tail_ticks() == (ran if _TAIL[0] == "2" else 0)
+    assert (eng.split_ticks() > 0) == (_TAIL[1] == "2")
 
 
 @pytest.mark.parametrize("chunk", [3, 10, 25])

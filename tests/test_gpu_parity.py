@@ -41,6 +41,8 @@ def car_layout(request):
 def step_path(request, monkeypatch):
     # "pairs": the per-tick kernels with two-tick passes (k_move_tt + k_edge) wherever a call has three ticks or more
     monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
+    monkeypatch.setenv("TFX_TAIL", "2")        # (with the pairs: k_tail behind every pass, csrc/tfx_tail.hpp,
+    monkeypatch.setenv("TFX_SPLIT", "2")       #  and the env range in two halves on two streams)
     if request.param.startswith("resident"):
         monkeypatch.setenv("TFX_RESIDENT", "1")
         monkeypatch.setenv("TFX_RES_EPB", "3")

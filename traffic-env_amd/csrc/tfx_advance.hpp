@@ -143,66 +143,71 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
   if (overflowed) d.done_tick[env] = tick + 1;
 }
 
+// One work item of the advance: s < I is intersection s of the env (its four incoming roads s, I+s, 2I+s, 3I+s,
+// roadgraph.py:38-39, plus the light words and the reward of that intersection), s >= I is exit road r + (s - I).
+// Item 0 of an env flagged for it runs the literal serial loop for the whole env.
+template <bool TL>
+__device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int tick, int tidx) {
+  if (env_frozen(d, env, tick)) return;  // stopped for the rest of this agent step
+  const bool serial = d.env_flag[env] == tick + 1;
+  if (serial && s == 0) {
+    if (TL) advance_env_serial_t(d, env, tick, tidx);
+    else advance_env_serial(d, env, tick, tidx);
+  }
+  if (s < d.I) {
+    int ph_new, el_new;
+    light_update(d, env, s, tick, tidx, ph_new, el_new);
+    if (!serial) {
+      int ovf = 0;
+#pragma unroll
+      for (int dir = 0; dir < 4; ++dir) {
+        const int e = dir * d.I + s;
+        ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
+      }
+      // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
+      float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
+      for (int j = 0; j < ovf; ++j) rw -= d.ovf_pen;
+      d.rewards[(size_t)env * d.I + s] = rw;
+      if (ovf > 0) d.done_tick[env] = tick + 1;
+    }
+    int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+    ob[s] = ph_new;
+    ob[d.I + s] = el_new;
+  } else if (!serial) {
+    const int e = d.r + (s - d.I);
+    const int ovf = TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx);
+    if (ovf > 0) d.done_tick[env] = tick + 1;
+    if (d.validate && d.n_trips && s == d.I) {
+      // advance_hack :153-154: trip times of cars leaving the map, in road order
+      int t = d.n_trips[env];
+      for (int x = d.r; x < d.R; ++x) {
+        const int idx = env * d.R + x;
+        const int rxx = d.rec[idx].x;
+        int ps = rec_head(rxx);
+        for (int j = 0; j < rec_kpop(rxx); ++j) {
+          // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed; <= 2 pops here)
+          const float cw = !d.w ? 0.0f : (TL ? d.outw[ocol_of(d, env, x) + (size_t)j * 64] : d.w[(size_t)idx * d.C + ps]);
+          if (d.trip_times && t < d.trip_cap)
+            d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
+          ++t;
+          ps = wrap1(ps + 1, d.C);
+        }
+      }
+      d.n_trips[env] = t;
+    }
+  }
+}
+
 template <bool TL>
 __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
   const int tick = *d.tickB;
-  const int n_exit = d.R - d.r;
-  const int per_env = d.I + n_exit;
+  const int per_env = d.I + (d.R - d.r);
   const long total = (long)d.E * per_env;
   for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
-    const int s = (int)(gid - (long)env * per_env);
     if (gid == 0) *d.tickA = tick + 1;
-    if (env_frozen(d, env, tick)) continue;  // stopped for the rest of this agent step
-    const bool serial = d.env_flag[env] == tick + 1;
-    if (serial && s == 0) {
-      if (TL) advance_env_serial_t(d, env, tick, tidx);
-      else advance_env_serial(d, env, tick, tidx);
-    }
-    if (s < d.I) {
-      // intersection s: its four incoming roads s, I+s, 2I+s, 3I+s (roadgraph.py:38-39)
-      int ph_new, el_new;
-      light_update(d, env, s, tick, tidx, ph_new, el_new);
-      if (!serial) {
-        int ovf = 0;
-#pragma unroll
-        for (int dir = 0; dir < 4; ++dir) {
-          const int e = dir * d.I + s;
-          ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
-        }
-        // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
-        float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
-        for (int j = 0; j < ovf; ++j) rw -= d.ovf_pen;
-        d.rewards[(size_t)env * d.I + s] = rw;
-        if (ovf > 0) d.done_tick[env] = tick + 1;
-      }
-      int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
-      ob[s] = ph_new;
-      ob[d.I + s] = el_new;
-    } else if (!serial) {
-      const int e = d.r + (s - d.I);
-      const int ovf = TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx);
-      if (ovf > 0) d.done_tick[env] = tick + 1;
-      if (d.validate && d.n_trips && s == d.I) {
-        // advance_hack :153-154: trip times of cars leaving the map, in road order
-        int t = d.n_trips[env];
-        for (int x = d.r; x < d.R; ++x) {
-          const int idx = env * d.R + x;
-          const int rxx = d.rec[idx].x;
-          int ps = rec_head(rxx);
-          for (int j = 0; j < rec_kpop(rxx); ++j) {
-            // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed; <= 2 pops here)
-            const float cw = !d.w ? 0.0f : (TL ? d.outw[ocol_of(d, env, x) + (size_t)j * 64] : d.w[(size_t)idx * d.C + ps]);
-            if (d.trip_times && t < d.trip_cap)
-              d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
-            ++t;
-            ps = wrap1(ps + 1, d.C);
-          }
-        }
-        d.n_trips[env] = t;
-      }
-    }
+    advance_item<TL>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
   }
 }
 

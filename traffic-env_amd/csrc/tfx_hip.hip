@@ -32,6 +32,7 @@
 #include "tfx_move_tt.hpp"
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
+#include "tfx_tail.hpp"
 #include "tfx_misc.hpp"
 
 using namespace tfx;
@@ -68,6 +69,15 @@ struct tfx_handle_s {
   int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
   int grid_adv = 0;
+  int grid_tail = 0;
+  int tail = 1;               // k_tail after a two-tick pass (tfx_tail.hpp): TFX_TAIL=0 never, 2 at any batch size
+  // calls of pairs run as TWO halves of the env range, the second on a stream of the handle's own: the latency-bound
+  // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)
+  int split = 1;              // TFX_SPLIT=0 never, 2 at any batch size
+  hipStream_t split_stream = nullptr;
+  hipEvent_t split_fork = nullptr, split_join = nullptr;
+  int *tick2 = nullptr;       // clock words of the second half (tickA, tickB), risk word
+  long long split_ticks = 0;  // ticks that ran split since tfx_create
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
   int *dev_tables = nullptr;  // nexts | pred | entry_idx | road_slot | slot_road
@@ -87,6 +97,8 @@ struct tfx_handle_s {
   bool prof = false;
   long long fused_ticks = 0;   // ticks run by k_res since tfx_create
   long long pair_ticks = 0;    // ticks run as two-tick passes since tfx_create
+  long long tail_ticks = 0;    // ... of which k_tail finished the pair (tfx_tail.hpp)
+  long long ag_fused = 0, ag_pair = 0;  // what ONE replay of the captured agent-step graph adds to the two above
   const char *step_kernel = "";  // the kernel that moved the cars in the last tick (tfx_step_kernel)
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
@@ -521,6 +533,86 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   return TFX_OK;
 }
 
+// The envs [lo, lo + n) of a handle as a Dev of their own: every per-env array starts at env lo, the global env
+// id offset moves along (on-device rules are functions of the global id), the vehicle-update counter is shared.
+Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
+  Dev s = h->d;
+  const Dev &d = h->d;
+  const size_t R = (size_t)d.R, I = (size_t)d.I, r = (size_t)d.r, L = (size_t)lo;
+  s.E = n;
+  s.env_off = d.env_off + lo;
+  const size_t tile_pairs = (size_t)d.G * (size_t)d.trows * 64, out_pairs = (size_t)d.G * KP * 64;
+  s.xv = d.xv + L * (d.layout == 1 ? tile_pairs : R * d.C);
+  if (d.w) s.w = d.w + L * (d.layout == 1 ? tile_pairs : R * d.C);
+  s.leading = d.leading + L * R;
+  s.lastcar = d.lastcar + L * R;
+  s.obs = d.obs + L * (size_t)d.obs_len;
+  s.rewards = d.rewards + L * I;
+  s.waiting = d.waiting + L * r;
+  s.passed_dst = d.passed_dst + L * I;
+  s.done_tick = d.done_tick + L;
+  if (d.trip_times) s.trip_times = d.trip_times + L * (size_t)d.trip_cap;
+  if (d.n_trips) s.n_trips = d.n_trips + L;
+  s.rec = d.rec + L * R;
+  s.rec2 = d.rec2 + L * R;
+  s.tailx = d.tailx + L * R;
+  s.leadx = d.leadx + L * R;
+  s.outb = d.outb + L * out_pairs;
+  if (d.outw) s.outw = d.outw + L * out_pairs;
+  s.env_flag = d.env_flag + L;
+  s.env_risk = d.env_risk + L;
+  if (d.action_mode == TFX_ACTION_BUFFER && d.action) s.action = d.action + L * I;
+  if (d.spawn_mode == TFX_SPAWN_COUNTS && d.spawn) s.spawn = d.spawn + L * (size_t)d.n_entry;
+  if (clock) {
+    s.tickA = clock;
+    s.tickB = clock + 1;
+    s.risk_any = clock + 2;
+  }
+  return s;
+}
+
+// k_tail (tfx_tail.hpp) replaces k_advance(t) k_edge(t+1) k_advance(t+1) behind a two-tick pass: one workgroup per
+// env.  Not when the inputs of t+1 are produced on the device between the two ticks (Poisson arrivals, greedy
+// controller), and not below one env per CU (a handful of big envs - cfg4 - has too few workgroups to offer).
+bool tail_usable(tfx_handle h) {
+  if (!h->tail || h->poisson || h->greedy || h->d.layout != 1 || h->d.w) return false;
+  return h->tail == 2 || h->d.E >= h->n_cu;
+}
+
+// Two halves on two streams: where each half still runs pairs with k_tail behind them (one env per CU and half).
+// Measured at cfg2, ms per tick, one range / two halves: 4096 envs 0.474 / 0.437, 2048 0.238 / 0.227, 1024
+// 0.128 / 0.121, 512 0.0759 / 0.0705.  Not while per-kernel timing is on (tfx_profile times launches that own
+// the chip).
+bool split_usable(tfx_handle h, int n_ticks) {
+  if (!h->split || h->prof || n_ticks < 2 || !pairs_usable(h, n_ticks) || !tail_usable(h)) return false;
+  if (h->d.E < 2) return false;
+  if (h->split == 2) return true;
+  return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
+}
+
+template <int THREADS>
+int launch_tail_n(tfx_handle h, int tidx, hipStream_t st) {
+  if (h->grid_tail == 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<THREADS>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (const char *pc = getenv("TFX_TAIL_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+    long g = (long)h->n_cu * per_cu;
+    if (g > h->d.E) g = h->d.E;
+    h->grid_tail = (int)(g < 1 ? 1 : g);
+  }
+  if (h->size_only) return TFX_OK;
+  hipLaunchKernelGGL(k_tail<THREADS>, dim3(h->grid_tail), dim3(THREADS), 0, st, h->d, tidx);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int launch_tail(tfx_handle h, int tidx, hipStream_t st) {
+  static const int threads = getenv("TFX_TAIL_THREADS") ? atoi(getenv("TFX_TAIL_THREADS")) : 256;
+  if (threads == 1024) return launch_tail_n<1024>(h, tidx, st);
+  if (threads == 512) return launch_tail_n<512>(h, tidx, st);
+  return launch_tail_n<256>(h, tidx, st);
+}
+
 template <bool AGENT>
 int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
   hipLaunchKernelGGL(k_edge<AGENT>, dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
@@ -540,8 +632,9 @@ namespace {
 
 // the launches of one agent step, in order, on `st`
 int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
-                   hipStream_t st) {
+                   hipStream_t st, long long &n_fused, long long &n_pair) {
   Dev &d = h->d;
+  n_fused = n_pair = 0;
   const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
   if (res_usable(h, n_ticks)) {
     // every tick of the decision AND its tail (remi, observation, rewards, done flags) in one launch
@@ -550,7 +643,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     const int rc = launch_res(h, n_ticks, st, 1, remi, aobs, areward, adone);
     d.agent_mode = keep_mode;
     d.accum_rewards = keep_acc;
-    if (rc == TFX_OK) h->fused_ticks += n_ticks;
+    if (rc == TFX_OK) n_fused = n_ticks;
     return rc;
   }
   hipLaunchKernelGGL(k_agent_begin, dim3(1), dim3(1), 0, st, d, const_cast<int *>(d.agent_first));
@@ -573,7 +666,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         if (rc == TFX_OK) rc = launch_edge<true>(h, t + 1, st);
         if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 1);
         if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
-        if (rc == TFX_OK) h->pair_ticks += 2;
+        if (rc == TFX_OK) n_pair += 2;
       }
     }
     for (; t < n_ticks && rc == TFX_OK; ++t) {
@@ -604,6 +697,55 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
 
 }  // namespace
 
+namespace {
+// the per-tick kernels for n_ticks ticks of the envs h->d describes (the whole handle, or one half of it), on st
+int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
+  int t = 0;
+  const bool tt = pairs_usable(h);
+  if (tt) {
+    for (; t + 1 < n_ticks; t += 2) {
+      const bool timed = h->prof && h->ev_used < h->ev_ticks;
+      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+      if (int rc = launch_inputs(h, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[0], st));
+      if (int rc = launch_move_tt<true>(h, t, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[1], st));
+      if (tail_usable(h)) {
+        if (int rc = launch_tail(h, t, st)) return rc;
+        h->tail_ticks += 2;
+      } else {
+        if (int rc = launch_advance(h, t, st)) return rc;
+        if (int rc = launch_inputs(h, st)) return rc;
+        if (int rc = launch_edge<false>(h, t + 1, st)) return rc;
+        if (int rc = launch_advance(h, t + 1, st)) return rc;
+      }
+      if (timed) {
+        HIPCHK(hipEventRecord(e[2], st));
+        h->ev_weight[h->ev_used] = 2;
+        ++h->ev_used;
+      }
+      h->pair_ticks += 2;
+    }
+  }
+  for (; t < n_ticks; ++t) {
+    const bool timed = h->prof && h->ev_used < h->ev_ticks;
+    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (int rc = launch_inputs(h, st)) return rc;
+    if (timed) HIPCHK(hipEventRecord(e[0], st));
+    if (int rc = tt ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
+    if (timed) HIPCHK(hipEventRecord(e[1], st));
+    if (int rc = launch_advance(h, t, st)) return rc;
+    if (timed) {
+      HIPCHK(hipEventRecord(e[2], st));
+      h->ev_weight[h->ev_used] = 1;
+      ++h->ev_used;
+    }
+  }
+  return TFX_OK;
+}
+
+}  // namespace
+
 extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
                               uint8_t *adone, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
@@ -613,7 +755,15 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
                             "with per_tick = 0)");
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
-  if (!h->use_graph) return agent_sequence(h, n_ticks, remi, aobs, areward, adone, st);
+  if (!h->use_graph) {
+    long long nf = 0, np = 0;
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np);
+    if (rc == TFX_OK) {
+      h->fused_ticks += nf;
+      h->pair_ticks += np;
+    }
+    return rc;
+  }
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[640];
   snprintf(key, sizeof key, "%llu|%u|%u|%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
@@ -642,7 +792,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       (void)edge_grid(h);
     }
     HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream);
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream, h->ag_fused, h->ag_pair);
     hipGraph_t g = nullptr;
     const hipError_t ce = hipStreamEndCapture(h->ag_stream, &g);
     if (rc != TFX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -652,6 +802,8 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     h->ag_key = key;
   }
   HIPCHK(hipGraphLaunch(h->ag_exec, st));
+  h->fused_ticks += h->ag_fused;  // (the capture ran no kernel: every replay counts)
+  h->pair_ticks += h->ag_pair;
   return TFX_OK;
 }
 
@@ -682,6 +834,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
   if (const char *gr = getenv("TFX_GRAPH")) h->use_graph = atoi(gr) != 0;
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
+  if (const char *tv = getenv("TFX_TAIL")) h->tail = atoi(tv);
+  if (const char *sv = getenv("TFX_SPLIT")) h->split = atoi(sv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -757,7 +911,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_opairs * sizeof(float2) : 0), 256);
   const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_opairs * sizeof(float) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + ER * sizeof(float), 256);
-  const size_t o_misc = off;  off = align_up(off + 64, 256);
+  const size_t o_misc = off;  off = align_up(off + 128, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {
     (void)hipFree(h->dev_tables);
@@ -785,6 +939,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tickB = (int *)(base + o_misc + 32);
   d.agent_first = (const int *)(base + o_misc + 48);
   d.risk_any = (int *)(base + o_misc + 56);
+  h->tick2 = (int *)(base + o_misc + 64);
   // reciprocal division is used only if it is exact for this handle's constants on the whole
   // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
   d.fastdiv = 0;
@@ -823,6 +978,12 @@ int tfx_destroy(tfx_handle h) {
   if (h->ag_exec) (void)hipGraphExecDestroy(h->ag_exec);
   if (h->ag_graph) (void)hipGraphDestroy(h->ag_graph);
   if (h->ag_stream) (void)hipStreamDestroy(h->ag_stream);
+  if (h->split_stream) {
+    (void)hipStreamSynchronize(h->split_stream);
+    (void)hipStreamDestroy(h->split_stream);
+    (void)hipEventDestroy(h->split_fork);
+    (void)hipEventDestroy(h->split_join);
+  }
   if (h->dev_ps) (void)hipFree(h->dev_ps);
   if (h->dev_greedy) (void)hipFree(h->dev_greedy);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
@@ -1003,43 +1164,42 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     }
     return TFX_OK;
   }
-  int t = 0;
-  const bool tt = pairs_usable(h);
-  if (tt) {
-    for (; t + 1 < n_ticks; t += 2) {
-      const bool timed = h->prof && h->ev_used < h->ev_ticks;
-      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
-      if (int rc = launch_inputs(h, st)) return rc;
-      if (timed) HIPCHK(hipEventRecord(e[0], st));
-      if (int rc = launch_move_tt<true>(h, t, st)) return rc;
-      if (timed) HIPCHK(hipEventRecord(e[1], st));
-      if (int rc = launch_advance(h, t, st)) return rc;
-      if (int rc = launch_inputs(h, st)) return rc;
-      if (int rc = launch_edge<false>(h, t + 1, st)) return rc;
-      if (int rc = launch_advance(h, t + 1, st)) return rc;
-      if (timed) {
-        HIPCHK(hipEventRecord(e[2], st));
-        h->ev_weight[h->ev_used] = 2;
-        ++h->ev_used;
-      }
-      h->pair_ticks += 2;
+  if (split_usable(h, n_ticks)) {
+    // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
+    if (!h->split_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
     }
-  }
-  for (; t < n_ticks; ++t) {
-    const bool timed = h->prof && h->ev_used < h->ev_ticks;
-    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
-    if (int rc = launch_inputs(h, st)) return rc;
-    if (timed) HIPCHK(hipEventRecord(e[0], st));
-    if (int rc = tt ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
-    if (timed) HIPCHK(hipEventRecord(e[1], st));
-    if (int rc = launch_advance(h, t, st)) return rc;
-    if (timed) {
-      HIPCHK(hipEventRecord(e[2], st));
-      h->ev_weight[h->ev_used] = 1;
-      ++h->ev_used;
+    if (h->grid_tt[1] == 0 || h->grid_tt[0] == 0 || h->grid_tail == 0) {  // grids are sized for the whole range
+      h->size_only = true;
+      (void)launch_move_tt<true>(h, 0, nullptr);
+      (void)launch_move_tt<false>(h, 0, nullptr);
+      (void)launch_tail(h, 0, nullptr);
+      (void)launch_advance(h, 0, nullptr);
+      h->size_only = false;
     }
+    const Dev whole = h->d;
+    const int n0 = whole.E / 2;
+    const long long pair0 = h->pair_ticks, tail0 = h->tail_ticks;
+    HIPCHK(hipEventRecord(h->split_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
+    int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
+    for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
+      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
+      rc = step_range(h, n_ticks, half == 0 ? st : h->split_stream);
+      h->d = whole;
+    }
+    if (rc != TFX_OK) return rc;
+    h->pair_ticks = pair0 + (h->pair_ticks - pair0) / 2;  // (both halves counted them)
+    h->tail_ticks = tail0 + (h->tail_ticks - tail0) / 2;
+    h->split_ticks += n_ticks;
+    HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+    HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
+    return TFX_OK;
   }
-  return TFX_OK;
+  return step_range(h, n_ticks, st);
 }
 
 int tfx_move_cars(tfx_handle h, void *stream) {
@@ -1195,6 +1355,18 @@ int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable) {
 int tfx_pair_ticks(tfx_handle h, int64_t *ticks) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->pair_ticks;
+  return TFX_OK;
+}
+
+int tfx_tail_ticks(tfx_handle h, int64_t *ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (ticks) *ticks = h->tail_ticks;
+  return TFX_OK;
+}
+
+int tfx_split_ticks(tfx_handle h, int64_t *ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (ticks) *ticks = h->split_ticks;
   return TFX_OK;
 }
 

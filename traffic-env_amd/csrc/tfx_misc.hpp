@@ -251,6 +251,12 @@ __global__ void k_done_since(const Dev d, uint8_t *out, const int *first) {
 // start of a fused agent step: remember the tick it starts at (env_frozen compares against it)
 __global__ void k_agent_begin(const Dev d, int *first) { *first = *d.tickA; }
 
+// the second half of a split call (tfx_step) keeps clock words of its own: brought up to date at the fork
+__global__ void k_clock_copy(const int *tickA, const int *tickB, int *clock2) {
+  clock2[0] = *tickA;
+  clock2[1] = *tickB;
+}
+
 // Repeater's observation (traffic_test.py:48-53): [sum of passed | last detected | elapsed/100 *
 // (2*phase - 1)] as float32, from the int obs the ticks left behind (passed accumulated in place).
 __global__ void k_agent_obs(const Dev d, float *aobs) {

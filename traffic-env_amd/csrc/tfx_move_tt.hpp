@@ -276,101 +276,103 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
 }
 
 // The second tick of a pair for the cars k_move_tt<true> could not take through it (see the head of this
-// file).  Runs after k_advance of the first tick; same tile / lane ownership as the pass, a few cars per road.
+// file), for the 64 roads of one tile: lane = road.  Runs after the advance of the first tick; same tile / lane
+// ownership as the pass, a few cars per road.  Returns the lane's vehicle-updates.
+template <bool AGENT>
+__device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx) {
+  const int C = d.C;
+  // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
+  // one-tick launch of their own)
+  if (AGENT && (d.env_risk[env] == tick || env_frozen(d, env, tick))) return 0;
+  const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+  if (e < 0) return 0;
+  const int id = env * d.R + e;
+  const int4 rc = d.rec[id];    // the pass's record of the first tick
+  const int4 r2 = d.rec2[id];
+  const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, true, true);
+  const int m0 = rc.w - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
+  const int n_old = p.n_old, n_tot = p.n_tot;
+
+  float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
+  float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+
+  // r2.y: the road's waiting count of the first tick plus the second tick's so far; r2.z: detected so far
+  int kpop = 0, n_wait = r2.y, n_det = r2.z;
+  bool open = true, far = false;
+  const int kq = C - 1 - p.ld;
+  float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
+  float tail_x = 0.0f;
+  // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll)
+  auto car = [&](int i, float x, float v) {
+    float zx, zv;
+    idm_step(d, x, v, lx, lv, ll, zx, zv);
+    lx = x;
+    lv = v;
+    ll = d.car_l;
+    const bool pop = open && (zx > d.length);
+    open = pop;
+    if (pop && kpop < KP) ocol[(size_t)kpop * 64] = make_float2(zx, zv);
+    else col[(size_t)i * 64] = make_float2(zx, zv);  // (a popped car beyond the outbox stays in its row: uncompacted)
+    if (pop) far = far || ((zx - d.length) > d.length);
+    kpop += pop ? 1 : 0;
+    const float wq = (i >= kq) ? zx : zv;
+    n_wait += (wq < d.thresh) ? 1 : 0;
+    n_det += (zx > d.near_end) ? 1 : 0;
+    tail_x = zx;
+  };
+  if (m0 > 0) {
+    const float2 head = col[0];
+    car(0, head.x, head.y);
+    // cars behind a head that left: already a tick ahead, the pop prefix may run on into them
+    for (int i = 1; i < m0 && open; ++i) {
+      const float2 z = col[(size_t)i * 64];
+      if (z.x > d.length) {
+        if (kpop < KP) ocol[(size_t)kpop * 64] = z;
+        far = far || ((z.x - d.length) > d.length);
+        ++kpop;
+      } else {
+        open = false;
+      }
+    }
+    if (m0 >= 2) {  // whoever queues behind the survivors follows the last one's tick-t state
+      lx = __int_as_float(rc.z);
+      lv = __int_as_float(r2.x);
+      tail_x = __int_as_float(r2.w);
+    }
+  }
+  for (int i = m0; i < n_old; ++i) {  // handed over by the first tick's advance
+    const float2 c = col[(size_t)i * 64];
+    car(i, c.x, c.y);
+  }
+  for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v);  // spawned this tick
+
+  const bool unc = kpop > KP;
+  if (e < d.r) {
+    int *ob = d.obs + (size_t)env * d.obs_len;
+    if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
+    if (n_tot > 0) ob[d.r + e] = n_det;
+    ob[e] = AGENT ? ob[e] + kpop : kpop;
+    if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+  }
+  d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
+                        __float_as_int(tail_x), n_tot);
+  if (far || unc) d.env_flag[env] = tick + 1;
+  d.leadx[id] = p.xL;
+  return n_tot;
+}
+
 template <bool AGENT>
 __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
-  const int C = d.C;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
 
   unsigned long long my_updates = 0;
-
-  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
-    const int env = (int)(tile / d.G);
-    // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
-    // one-tick launch of their own)
-    if (AGENT && (d.env_risk[env] == tick || env_frozen(d, env, tick))) continue;
-    const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
-    if (e_slot < 0) continue;
-    const int e = e_slot;
-    const int id = env * d.R + e;
-    const int4 rc = d.rec[id];    // the pass's record of the first tick
-    const int4 r2 = d.rec2[id];
-    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, true, true);
-    const int m0 = rc.w - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
-    const int n_old = p.n_old, n_tot = p.n_tot;
-
-    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
-    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
-
-    // r2.y: the road's waiting count of the first tick plus the second tick's so far; r2.z: detected so far
-    int kpop = 0, n_wait = r2.y, n_det = r2.z;
-    bool open = true, far = false;
-    const int kq = C - 1 - p.ld;
-    float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
-    float tail_x = 0.0f;
-    // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll)
-    auto car = [&](int i, float x, float v) {
-      float zx, zv;
-      idm_step(d, x, v, lx, lv, ll, zx, zv);
-      lx = x;
-      lv = v;
-      ll = d.car_l;
-      const bool pop = open && (zx > d.length);
-      open = pop;
-      if (pop && kpop < KP) ocol[(size_t)kpop * 64] = make_float2(zx, zv);
-      else col[(size_t)i * 64] = make_float2(zx, zv);  // (a popped car beyond the outbox stays in its row: uncompacted)
-      if (pop) far = far || ((zx - d.length) > d.length);
-      kpop += pop ? 1 : 0;
-      const float wq = (i >= kq) ? zx : zv;
-      n_wait += (wq < d.thresh) ? 1 : 0;
-      n_det += (zx > d.near_end) ? 1 : 0;
-      tail_x = zx;
-    };
-    if (m0 > 0) {
-      const float2 head = col[0];
-      car(0, head.x, head.y);
-      // cars behind a head that left: already a tick ahead, the pop prefix may run on into them
-      for (int i = 1; i < m0 && open; ++i) {
-        const float2 z = col[(size_t)i * 64];
-        if (z.x > d.length) {
-          if (kpop < KP) ocol[(size_t)kpop * 64] = z;
-          far = far || ((z.x - d.length) > d.length);
-          ++kpop;
-        } else {
-          open = false;
-        }
-      }
-      if (m0 >= 2) {  // whoever queues behind the survivors follows the last one's tick-t state
-        lx = __int_as_float(rc.z);
-        lv = __int_as_float(r2.x);
-        tail_x = __int_as_float(r2.w);
-      }
-    }
-    for (int i = m0; i < n_old; ++i) {  // handed over by the first tick's advance
-      const float2 c = col[(size_t)i * 64];
-      car(i, c.x, c.y);
-    }
-    for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v);  // spawned this tick
-
-    const bool unc = kpop > KP;
-    if (e < d.r) {
-      int *ob = d.obs + (size_t)env * d.obs_len;
-      if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
-      if (n_tot > 0) ob[d.r + e] = n_det;
-      ob[e] = AGENT ? ob[e] + kpop : kpop;
-      if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
-    }
-    d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
-                          __float_as_int(tail_x), n_tot);
-    if (far || unc) d.env_flag[env] = tick + 1;
-    d.leadx[id] = p.xL;
-    my_updates += (unsigned long long)n_tot;
-  }
+  for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw)
+    my_updates += (unsigned long long)edge_tile<AGENT>(d, tile, (int)(tile / d.G), lane, tick, tick_sp, tidx);
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if (lane == 0 && my_updates) veh_add(d.veh, my_updates);

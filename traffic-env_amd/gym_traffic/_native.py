@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib",
 
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class TfxConfig(C.Structure):
@@ -72,6 +72,8 @@ _PROTOS = {
                                       C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "tfx_fused_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tfx_pair_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tfx_tail_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tfx_split_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_step_kernel": (C.c_char_p, [C.c_void_p]),
 }
 

@@ -523,6 +523,18 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_pair_ticks(self.h, C.byref(n)))
         return int(n.value)
 
+    def tail_ticks(self):
+        """Ticks of those whose pair was finished by ONE launch, a workgroup per env (k_tail; tfx_tail_ticks)."""
+        n = C.c_int64()
+        nat.check(self.lib.tfx_tail_ticks(self.h, C.byref(n)))
+        return int(n.value)
+
+    def split_ticks(self):
+        """Ticks of step() calls that ran as two halves of the env range on two streams (tfx_split_ticks)."""
+        n = C.c_int64()
+        nat.check(self.lib.tfx_split_ticks(self.h, C.byref(n)))
+        return int(n.value)
+
     def step_kernel(self):
         """Name of the kernel that moved the cars in the last tick ('k_move_t', 'k_res', ...)."""
         return self.lib.tfx_step_kernel(self.h).decode()

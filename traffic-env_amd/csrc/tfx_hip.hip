@@ -197,13 +197,13 @@ int check_handle(tfx_handle h, bool need_bound) {
 // Grid of the move kernel: every block resident at once (occupancy query), a multiple of 8 so the
 // XCD-contiguous chunking applies, never more blocks than there is work.
 template <typename K>
-int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds = 0) {
+int move_grid(tfx_handle h, K kernel, long work_items_per_block, size_t dyn_lds = 0, int cap = 5) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess || per_cu < 1)
     per_cu = 4;
   // more resident waves than ~5 blocks per CU only adds concurrent DRAM streams: measured at cfg2
-  // 3/4/5/6/7/8 blocks per CU -> 0.763/0.721/0.711/0.720/0.804/0.761 ms
-  if (per_cu > 5) per_cu = 5;
+  // 3/4/5/6/7/8 blocks per CU -> 0.763/0.721/0.711/0.720/0.804/0.761 ms (k_move_t; k_move_tt takes 6, see there)
+  if (per_cu > cap) per_cu = cap;
   if (const char *pc = getenv("TFX_MOVE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
   const long total = h->d.layout == 1 ? (long)h->d.E * h->d.G * 64 : (long)h->d.E * h->d.R;
   const long need = (total + work_items_per_block - 1) / work_items_per_block;
@@ -525,7 +525,7 @@ int edge_grid(tfx_handle h) {
 template <bool TWO, bool AGENT = false>
 int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   int &grid = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
-  if (grid == 0) grid = move_grid(h, k_move_tt<TWO, AGENT>, 256);
+  if (grid == 0) grid = move_grid(h, k_move_tt<TWO, AGENT>, 256, 0, 6);
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
   hipLaunchKernelGGL((k_move_tt<TWO, AGENT>), dim3(grid), dim3(256), 0, st, h->d, tidx, only_risky);

@@ -48,9 +48,19 @@ namespace tfx {
 // AGENT: inside an agent step - frozen envs are skipped, `passed` accumulates over the step, tiles of risky
 // envs (env_risk == tick + 1) take the one-tick form; only_risky: nothing but the tiles of envs marked risky
 // for the pair that began one tick earlier (the second tick of those envs)
+#ifndef TT_P
+#define TT_P 4
+#endif
+// Six wavefronts per SIMD (<= 80 vector registers).  Measured at cfg2 (ms per pass, alone on the chip / vehicle-updates
+// per second of the split call): 5 per SIMD (81 registers, what the compiler picks) 0.764 / 4.92e11, 6: 0.745 / 5.22e11,
+// 7: 0.728 / 5.04e11, 8: 0.746 / 4.98e11 - at 6 the pass leaves room for one k_tail wavefront per SIMD beside it.
+#ifndef TT_WAVES
+#define TT_WAVES 6
+#endif
+#define TT_ATTR __attribute__((amdgpu_waves_per_eu(TT_WAVES, TT_WAVES)))
 template <bool TWO, bool AGENT = false>
-__global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
-  constexpr int P = 4;
+__global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int tidx, const int only_risky) {
+  constexpr int P = TT_P;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
@@ -118,6 +128,8 @@ __global__ __launch_bounds__(256) void k_move_tt(const Dev d, const int tidx, co
     auto step = [&](int k, float x, float v, auto last) {
       constexpr bool LAST = decltype(last)::value;
       float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
+      // (one wave-wide test per row.  Round 3 measured the alternatives on this kernel: the speeds read from memory
+      // tested once per group of P rows, 0.772 ms per pass against 0.764; no test at all - results wrong - 0.734)
       const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v));
       const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
       if (d.fastdiv && !off_domain) {

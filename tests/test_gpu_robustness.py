@@ -151,3 +151,24 @@ def test_fuzz_small_configurations_vs_oracle():
             assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (trial, t)
             t += k
             assert_same_state(eng, orc, "trial %d (%dx%d C=%d E=%d %s) tick %d" % (trial, m, n, C, E, layout, t))
+
+
+def test_refresh_refuses_a_stale_staging_copy():
+    """An edit through a reference to eng.xv kept across a step must not be dropped silently (nor pushed over the
+    live cars): refresh() raises, a fresh access + edit + refresh() lands."""
+    from gym_traffic import workload as wl
+    from gym_traffic._native import TfxError
+    eng = wl.setup_engine("cfg1", envs=4)
+    xv = eng.xv                      # staging copy, fresh
+    eng.step(3)                      # the cars move: `xv` is stale now
+    xv[0, 0, 2, 0] = 123.0
+    with pytest.raises(TfxError):
+        eng.refresh()
+    eng.refresh(cars=False)          # explicit: tails only, the cars stay as they are
+    fresh = eng.xv
+    assert float(fresh[0, 0, 2, 0]) != 123.0
+    ld = int(eng.leading[0, 5])
+    slot = ld + 1 if ld + 1 < eng.C else 1
+    fresh[0, 5, slot, 1] = 0.25      # the head car of road 5 slows down
+    eng.refresh()
+    assert float(eng.xv[0, 5, slot, 1]) == 0.25

@@ -54,7 +54,7 @@ def _run(rng, seed, LIMIT):
         layout = str(rng.choice(["ring", "transposed", "transposed"]))
         os.environ.pop("TFX_KINDS", None); os.environ.pop("TFX_MOVE_VARIANT", None)
         mode = rng.randint(3)
-        mv = int(rng.choice([0, 0, 91, 94, 98]))      # launch heuristics | streaming kernels forced at any size
+        mv = int(rng.choice([0, 0, 91]))      # launch heuristics | streaming kernels forced at any size
         if layout == "transposed" and mv: os.environ["TFX_MOVE_VARIANT"] = str(mv)
         os.environ["TFX_RESIDENT"] = "1" if mode == 1 else "0"      # LDS-resident multi-tick kernel | per-tick kernels
         os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))

@@ -20,7 +20,6 @@ constexpr int KP = TFX_KP;
 struct Dev {
   int I, r, R, C, E, n_entry, obs_len;
   int yellow, learn_switch, validate, env_off;
-  int dbg;  // TFX_DEBUG ablation bits (timing experiments only; results are wrong when set)
   // fused agent step (Repeater + Remi, traffic_test.py:27-64): `passed` (and, without Remi, the
   // rewards) accumulate over the ticks of the step; an env that overflowed in an earlier tick of
   // the step stands still for the rest of it (`if done: break`, traffic_test.py:55)

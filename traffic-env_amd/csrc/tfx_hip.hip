@@ -5,7 +5,7 @@
 //   * for envs that fit a compute unit's LDS: part of ONE launch per tfx_step / tfx_agent_step call -
 //     k_res (tfx_resident.hpp), the cars resident on chip for all the ticks of the call;
 //   * otherwise two kernels:
-//       k_move_t / k_move_ts (transposed layout: tfx_move_t.hpp, tfx_move_ts.hpp; A/B: tfx_move_t2.hpp)
+//       k_move_t / k_move_ts (transposed layout: tfx_move_t.hpp, tfx_move_ts.hpp)
 //       or k_move_dma / k_move<WPR> (ring layout: tfx_move_dma.hpp, tfx_move_generic.hpp)
 //                                                          lights, spawns, IDM, counts, compaction
 //       k_advance (tfx_advance.hpp, tfx_advance_t.hpp)     ring pop + handoff, rewards, light words
@@ -27,7 +27,6 @@
 #include "tfx_move_generic.hpp"
 #include "tfx_move_dma.hpp"
 #include "tfx_move_t.hpp"
-#include "tfx_move_t2.hpp"
 #include "tfx_move_ts.hpp"
 #include "tfx_move_tt.hpp"
 #include "tfx_resident.hpp"
@@ -240,8 +239,8 @@ int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
   return TFX_OK;
 }
 
-// Transposed layout.  TFX_MOVE_VARIANT: 0 = automatic | 54/58/68/88 k_move_t A/B points | 90/91 force /
-// forbid the four-waves-per-tile kernel
+// Transposed layout.  TFX_MOVE_VARIANT: 0 = automatic | 90 / 91 force / forbid the four-waves-per-tile kernel
+// (tests run k_move_t at sizes the heuristics would give to k_move_ts)
 int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   const int pvar = h->move_variant;
   auto go = [&](auto kern) {
@@ -259,7 +258,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   // 0.083; no gain at cfg2 x 64 (1088) and a loss at cfg1 x 1024 (1280): there the redundant road
   // prologues outweigh the shorter walks
   const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
-  if (pvar == 90 || (tiles <= split_below && (pvar == 0 || (pvar >= 100 && pvar < 110)))) {
+  if (pvar == 90 || (tiles <= split_below && pvar == 0)) {
     auto gs = [&](auto kern) {
       if (h->grid_move == 0) h->grid_move = (int)(tiles < (long)h->n_cu * 8 ? tiles : (long)h->n_cu * 8);
       if (h->size_only) return (int)TFX_OK;
@@ -280,19 +279,6 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     { h->step_kernel = "k_move_ts"; return gs(k_move_ts<64>); }
   }
   if (h->d.w) { h->step_kernel = "k_move_t"; return go(k_move_t<4, 3, true>); }  // validate mode: the spawn-tick plane travels along
-  // k_move_t2 (tfx_move_t2.hpp): packed-pair arithmetic, one domain test per group of 2 / 4 / 8 rows -
-  // a third fewer vector instructions, bit-identical, and measured 2-3 % SLOWER than k_move_t at cfg2
-  // (same box: 0.670 / 0.664 / 0.678 ms against 0.651): the launch is not VALU-limited.
-  // Kept as A/B points (102 / 104 / 108; 92 / 94 / 98 = the same, never the four-waves-per-tile kernel).
-  if (pvar == 102 || pvar == 92) { h->step_kernel = "k_move_t2"; return go(k_move_t2<2>); }
-  if (pvar == 104 || pvar == 94) { h->step_kernel = "k_move_t2"; return go(k_move_t2<4>); }
-  if (pvar == 108 || pvar == 98) { h->step_kernel = "k_move_t2"; return go(k_move_t2<8>); }
-  // A/B points kept from the tuning runs
-  if (pvar == 51) { h->step_kernel = "k_move_t"; return go(k_move_t<1, 3>); }
-  if (pvar == 52) { h->step_kernel = "k_move_t"; return go(k_move_t<2, 3>); }
-  if (pvar == 54) { h->step_kernel = "k_move_t"; return go(k_move_t<4>); }           // default caching policy (0.82 ms at cfg2)
-  if (pvar == 58) { h->step_kernel = "k_move_t"; return go(k_move_t<8>); }
-  if (pvar == 68) { h->step_kernel = "k_move_t"; return go(k_move_t<8, 3>); }
   // Cars that fit the 256 MiB Infinity Cache (+ L2) are found there again next tick: default caching
   // and 8 rows in flight.  Measured k_move_t<8> vs <4, nt> per launch: cfg2 x 128 envs (143 MB of cars)
   // 0.0365 vs 0.0392 ms, x 256 0.048 vs 0.054, x 384 0.068 vs 0.080, x 512 (286 MB) 0.086 vs 0.093,
@@ -304,7 +290,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   { h->step_kernel = "k_move_t"; return go(k_move_t<4, 3>); }
 }
 
-// Ring layout.  TFX_MOVE_VARIANT: 0 = automatic | 1 generic k_move<1> | 21/24/26/34 k_move_dma A/B points
+// Ring layout.  TFX_MOVE_VARIANT: 0 = automatic | 1 generic k_move<1> | 26 k_move_dma with the capacity read at run time
 int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (h->d.layout == 1) return launch_move_t(h, tidx, st);
   const int C = h->d.C;
@@ -320,12 +306,7 @@ int launch_move(tfx_handle h, int tidx, hipStream_t st) {
   if (v == 0 && (long)h->d.E * h->d.R < 64L * h->n_cu) return launch_generic<1>(h, tidx, st);
   if (C == 34) return launch_dma<34, 8, 2, 4, false, 2>(h, tidx, st);   // cfg1
   if (C != 66 || v == 26) return launch_dma<0, 8, 1, 8, false>(h, tidx, st);  // capacity read at run time
-  switch (v) {  // C == 66 (cfg2): A/B points kept from the tuning runs
-    case 21: return launch_dma<66, 8, 2, 8, false>(h, tidx, st);      // whole image written back
-    case 24: return launch_dma<66, 8, 2, 8, true>(h, tidx, st);       // leader through LDS instead of DPP
-    case 34: return launch_dma<66, 8, 3, 8, false, 2>(h, tidx, st);   // three sub-tiles in flight
-    default: return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);   // best measured
-  }
+  return launch_dma<66, 8, 2, 4, false, 2>(h, tidx, st);  // cfg2: best of the tuning runs
 }
 
 // sizes the move kernel's grid without launching (the occupancy queries must not run inside a
@@ -382,13 +363,18 @@ bool res_try(tfx_handle h, int epb) {
     if (per_cu > cap) per_cu = cap;
     if (per_cu < 1) per_cu = 1;
     const size_t padded = ((size_t)160 * 1024 / (size_t)per_cu) & ~(size_t)255;
-    if (!getenv("TFX_RES_NOPAD") && padded > lds) lds = padded;
+    if (grid >= h->n_cu && padded > lds) lds = padded;  // (a launch that cannot fill the chip has nothing to even out)
   }
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<LPR, W>)),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;  // the runtime does not grant that much LDS
+  // The attribute belongs to the FUNCTION, not to the handle: handles with different LDS needs share it, so it is
+  // only ever raised (a later, smaller handle must not pull it below what an earlier one launches with).
+  static size_t granted = 64 * 1024;  // per instantiation <LPR, W>, process-wide
+  if (lds > granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(static_cast<void (*)(const Dev, const ResArgs)>(k_res<LPR, W>)),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;  // the runtime does not grant that much LDS
+    }
+    granted = lds;
   }
   h->res_lpr = LPR;
   h->res_epb = epb;
@@ -480,7 +466,6 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_advance<false>, 256, 0);
     if (qe != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 8) per_cu = 8;
-    if (const char *pc = getenv("TFX_ADVANCE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
     long g = (items + 255) / 256;
     if (g > (long)h->n_cu * per_cu) g = (long)h->n_cu * per_cu;
     h->grid_adv = (int)(g < 1 ? 1 : g);
@@ -512,7 +497,6 @@ int edge_grid(tfx_handle h) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_edge<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 6) per_cu = 6;  // measured at cfg2, 4 / 5 / 6 / 7 blocks per CU: 0.112 / 0.102 / 0.097 / 0.118 ms
-    if (const char *pc = getenv("TFX_EDGE_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
     const long tiles = (long)h->d.E * h->d.G;
     long g = (long)h->n_cu * per_cu;
     if (g > (tiles + 3) / 4) g = (tiles + 3) / 4;
@@ -590,27 +574,20 @@ bool split_usable(tfx_handle h, int n_ticks) {
   return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
 }
 
-template <int THREADS>
-int launch_tail_n(tfx_handle h, int tidx, hipStream_t st) {
+// (256 lanes per workgroup and as many workgroups as fit, measured at cfg2 against 512 / 1024 lanes and 2 / 3
+// workgroups per CU: 0.088 ms per tick against 0.090-0.131 - the launch lives on wavefronts in flight)
+int launch_tail(tfx_handle h, int tidx, hipStream_t st) {
   if (h->grid_tail == 0) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<THREADS>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (const char *pc = getenv("TFX_TAIL_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     long g = (long)h->n_cu * per_cu;
     if (g > h->d.E) g = h->d.E;
     h->grid_tail = (int)(g < 1 ? 1 : g);
   }
   if (h->size_only) return TFX_OK;
-  hipLaunchKernelGGL(k_tail<THREADS>, dim3(h->grid_tail), dim3(THREADS), 0, st, h->d, tidx);
+  hipLaunchKernelGGL(k_tail, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
-}
-
-int launch_tail(tfx_handle h, int tidx, hipStream_t st) {
-  static const int threads = getenv("TFX_TAIL_THREADS") ? atoi(getenv("TFX_TAIL_THREADS")) : 256;
-  if (threads == 1024) return launch_tail_n<1024>(h, tidx, st);
-  if (threads == 512) return launch_tail_n<512>(h, tidx, st);
-  return launch_tail_n<256>(h, tidx, st);
 }
 
 template <bool AGENT>
@@ -855,7 +832,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.validate = cfg->validate;
   d.env_off = cfg->env_id_offset;
   d.layout = cfg->layout;
-  if (const char *dbg = getenv("TFX_DEBUG")) d.dbg = atoi(dbg);
   d.length = cfg->length;
   d.rate = cfg->rate;
   d.car_v = cfg->car_v; d.car_l = cfg->car_l; d.car_a = cfg->car_a; d.car_v0 = cfg->car_v0;

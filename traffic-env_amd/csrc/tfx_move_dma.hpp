@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
           go = go && ((s0 > 0 && p0 < nr) || p1 < nr);
           bits |= go ? (1u << i) : 0u;
         }
-        if (go && !(d.dbg & 4))
+        if (go)
           __builtin_amdgcn_global_load_lds((gptr_t *)(gsrc + (size_t)q * 2), (lptr_t *)(dst + (size_t)q0 * 2), 16, 0, 0);
       }
       return bits;
@@ -179,8 +179,6 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
         wait_vmcnt<0>();
       }
       slotb = (slotb + 1 >= NBUF) ? 0 : slotb + 1;
-
-      if (d.dbg & 8) continue;  // ablation: DMA (and phases M, W) only
 
       // One road: lane k <-> the k-th car behind the fake leader.  SPAWN = false is the common case
       // (no car entered this road this tick): straight-line code, so the unrolled bodies of a
@@ -237,10 +235,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
           // down the IEEE-divide path.  Wave-uniform branch.
           const unsigned long long off_domain =
               __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) & lane_mask_below(n_totj - pp * 64);
-          if (d.dbg & 2) {  // ablation: no IDM arithmetic
-            xn = x + (xl - llp);
-            vn = v + vl;
-          } else if (d.fastdiv && off_domain == 0ull) {
+          if (d.fastdiv && off_domain == 0ull) {
             idm_step_fast(d, x, v, xl, vl, llp, xn, vn);
           } else {
             idm_step(d, x, v, xl, vl, llp, xn, vn);
@@ -296,7 +291,7 @@ __global__ __launch_bounds__(256) void k_move_dma(const Dev d, const int tidx) {
         int i = 0;
         for (int q0 = 0; q0 < n16; q0 += 64, ++i) {
           const int q = q0 + lane;
-          if (q < n16 && (LIVE < 2 || ((live_cur >> i) & 1u)) && !(d.dbg & 1)) dst4[q] = src4[q];
+          if (q < n16 && (LIVE < 2 || ((live_cur >> i) & 1u))) dst4[q] = src4[q];
         }
       }
     }

@@ -115,15 +115,12 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     auto step = [&](int k, float x, float v, float wv) {
       float xn, vn;
       const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
-      if (d.dbg & 64) {  // timing ablation: no arithmetic (results are wrong)
-        xn = x;
-        vn = v;
-      } else if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+      if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
       else idm_step(d, x, v, xprev, vprev, llv, xn, vn);
       xprev = x;  // OLD state leads the next car (Jacobi)
       vprev = v;
       llv = d.car_l;
-      const bool pop = open && (xn > d.length) && !(d.dbg & 128);  // the while loop of :123 (128: ablation)
+      const bool pop = open && (xn > d.length);  // the while loop of :123
       open = pop;
       if (pop) {
         if (kpop < KP) {

@@ -30,7 +30,7 @@
 #pragma once
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
-#include "tfx_move_t2.hpp"
+#include "tfx_idm_pair.hpp"
 #include "tfx_misc.hpp"
 
 namespace tfx {

@@ -23,8 +23,7 @@
 
 namespace tfx {
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_tail(const Dev d, const int tidx) {
+__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwv = blockDim.x >> 6;

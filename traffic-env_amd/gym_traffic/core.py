@@ -271,15 +271,23 @@ class TfxEngine(object):
         self._keep = (ph, m)
         self.done.masked_fill_(m.bool(), 0)
 
-    def refresh(self):
+    def refresh(self, cars=None):
         """After writing xv / leading / lastcar from outside: push the ring-layout staging copy to
-        the device layout (transposed handles) and rebuild the tail cache.  The staging copy is pushed
-        only if it was brought up to date (an `xv` / `x` / `v` / `w` access, `_export()` or
-        load_state) since the cars last moved - a stale one would overwrite the live cars.  Ring
-        semantics for a write to leading / lastcar alone therefore need `_export()` BEFORE the write
-        (the env's DeviceViews do that); without it the k-th car of a road stays its k-th car."""
+        the device layout (transposed handles) and rebuild the tail cache.
+
+        The staging copy mirrors the device only until the cars move again.  A caller that kept a
+        reference to `xv` / `x` / `v` / `w` across a step and wrote into it holds a STALE image: pushing
+        it would overwrite the live cars, dropping it would silently lose the edit - so that raises.
+        Take `eng.xv` again after the step (the access refreshes it), then write, then refresh().
+        cars=False: rebuild the tail cache only (the caller changed leading / lastcar alone and wants
+        the k-th car of a road to stay its k-th car); ring semantics for such a write need `_export()`
+        BEFORE it (the env's DeviceViews do that)."""
         with torch.cuda.device(self.device):
-            if self._t is not None and self._ring is not None and self._stage_epoch == self._epoch:
+            if self._t is not None and self._ring is not None and cars is not False:
+                if self._stage_epoch != self._epoch:
+                    raise nat.TfxError("refresh(): the ring-layout staging copy behind xv / x / v / w is stale (the cars "
+                                       "moved since it was exported); read eng.xv again before editing it, call "
+                                       "drop_staging() to discard it, or refresh(cars=False) to rebuild the tails only")
                 nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 

@@ -47,6 +47,7 @@ extern "C" {
 
 #define TFX_ABI_VERSION 10
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
+#define TFX_MAX_ARCH 8 /* rows of the archetype table (traffic_env.py:35-43 ships one) */
 
 enum {
   TFX_OK = 0,
@@ -103,6 +104,16 @@ typedef struct tfx_config {
                             down (the handle remembers where: two-tick passes, tfx_pair_ticks), so T is
                             meaningful only together with its handle - snapshot, restore or edit the cars
                             through tfx_export_ring / tfx_import_ring, never through T itself */
+  /* The reference's `archetypes` TABLE (traffic_env.py:35-43: float32 [n][10]; add_new_cars draws a row per car,
+   * :164).  n_archetypes <= 1: the single archetype of the car_* fields above (the reference's default), and the
+   * table is ignored.  n_archetypes in 2..TFX_MAX_ARCH, or one row whose delta is not 4: "heterogeneous cars" -
+   * every car carries the row it was spawned from through handoffs; needs layout = 1 and planes = 3 (the per-car
+   * side word then holds 8 * spawn tick + row), runs on the tick-by-tick kernels, and takes the rows of spawned
+   * cars from tfx_set_spawn_archetypes.  delta must be an integer in 1..8: (v/v0)**delta is the binary64 product
+   * chain of oracle/idm_oracle.c powi_cr rounded once (for 4: the same value as the single-archetype path).
+   * Row layout: v (spawn speed), l, a, delta, v0, b, T, s0. */
+  int32_t n_archetypes;
+  float arch[TFX_MAX_ARCH][8];
 } tfx_config;
 
 typedef struct tfx_buffers {
@@ -155,6 +166,12 @@ int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t perio
  * P(gap <= k) * 2^32 for k = 0.. (the last entry must be 0xFFFFFFFF); gym_traffic/devrng.py builds it
  * and mirrors the stream on the host. */
 int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uint32_t *cdf, int32_t n_cdf);
+/* Heterogeneous cars only: the archetype row of every car the count buffer of tfx_set_spawns adds
+ * (`archetypes[random.randint(archetypes.shape[0])]`, traffic_env.py:164): device uint8
+ * [n_ticks or 1][E][n_entry][per_road], entry j of a road = its j-th car of the tick in creation order (cars
+ * beyond per_road, and every car while no buffer is bound or under TFX_SPAWN_PERIODIC - the reference's `regular`
+ * generator yields archetypes[0], :174 - get row 0). */
+int tfx_set_spawn_archetypes(tfx_handle h, const uint8_t *dev, int32_t per_road, int32_t per_tick);
 
 /* TrafficEnv._step (traffic_env.py:224-248), n_ticks times: phase/elapsed update, spawns,
  * move_cars, advance_finished_cars | advance_hack, steps += 1. */
@@ -199,10 +216,11 @@ int tfx_profile_read(tfx_handle h, double *move_ms, double *advance_ms, int32_t 
 int tfx_xv_pairs(tfx_handle h, int64_t *pairs);
 /* Transposed-layout handles: copy the cars to / from ring-layout arrays (device pointers): ring_xv
  * float32 [E][R][C][2] with the fake leader's x in slot `leading` as the reference keeps it, ring_w
- * float32 [E][R][C] (spawn ticks; may be NULL, ignored unless planes = 3).  After an import call
+ * float32 [E][R][C] (spawn ticks; may be NULL, ignored unless planes = 3), ring_a uint8 [E][R][C] (archetype
+ * row per car; may be NULL, ignored unless the handle has heterogeneous cars).  After an import call
  * tfx_refresh. */
-int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, void *stream);
-int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, void *stream);
+int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, uint8_t *ring_a, void *stream);
+int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, const uint8_t *ring_a, void *stream);
 
 /* Two of the IDM's three divisions have a constant divisor (2*sqrt(a*b) and v0).  At tfx_create the
  * library checks on the device, exhaustively over the admitted numerator range, that the

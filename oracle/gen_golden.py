@@ -37,7 +37,7 @@ SCENARIOS = {}
 def scen(name, **kw):
     d = dict(m=2, n=2, L=250.0, C=20, seed=0, T=300, poisson=True, rate=0.5, lcps=0.12,
              entry='all', learn_switch=False, mode='train', actions='random10',
-             remi_every=10, state_every=1, state_next=False, mid=False)
+             remi_every=10, state_every=1, state_next=False, mid=False, archetypes=None)
     d.update(kw)
     SCENARIOS[name] = d
 
@@ -61,6 +61,12 @@ scen("g16x16_cfg2_ints", m=16, n=16, L=400.0, C=66, seed=0, T=150, lcps=0.25, st
 # grow past 64 cars (from tick ~130), reach 128, overflow (from tick 206) and wrap their rings (14 000 wrapped
 # road-ticks) while they keep handing cars over; car states of ticks 20 j and 20 j + 1 (teacher-forced floats)
 scen("g8x8_c130", m=8, n=8, L=800.0, C=130, seed=6, T=700, poisson=False, lcps=1.0, state_every=20, state_next=True)
+# More than the one archetype the reference ships (traffic_env.py:35-43 is a TABLE, :164 draws a row per car): the
+# default car, a long slow truck and a short quick car with delta = 2.  Rows: v, l, a, delta, v0, b, T, s0.
+scen("g2x2_three_archetypes", seed=7, T=300, lcps=0.25,
+     archetypes=[[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 4, 10.0, 4, 2.5, 2], [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1]])
+scen("g3x3_two_archetypes_c10", m=3, n=3, C=10, seed=8, T=300, lcps=0.2,
+     archetypes=[[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 4, 10.0, 4, 2.5, 2]])
 # config 5 itself for the first 130 ticks (integers only): 64x64, Poisson arrivals at the default rate
 scen("g64x64_c130_ints", m=64, n=64, L=800.0, C=130, seed=0, T=130, state_every=0)
 
@@ -78,6 +84,23 @@ def run(name, sc, mods):
                       learn_switch=bool(sc["learn_switch"]), mode=sc["mode"])
     C = te.CAPACITY
     xi, vi, wi = te.xi, te.vi, te.wi
+    keep_archetypes = te.archetypes
+    arch_cols = [te.vi, te.li, te.ai, te.deltai, te.v0i, te.bi, te.ti, te.s0i]
+    if sc.get("archetypes"):
+        tab = np.zeros((len(sc["archetypes"]), te.params), np.float32)
+        tab[:, arch_cols] = np.asarray(sc["archetypes"], np.float32)
+        te.archetypes = tab
+    spawn_arch_log = []     # archetype row of every car spawned in the current tick
+
+    def arch_of(state):
+        """Row of te.archetypes each slot's car was copied from (by its length, accel, ... - everything but x, v, w);
+        -1 where no row matches (dead slots, fake leaders)."""
+        key = state[:, [te.li, te.ai, te.deltai, te.v0i, te.bi, te.ti, te.s0i], :]          # [R, 7, C]
+        rows = te.archetypes[:, [te.li, te.ai, te.deltai, te.v0i, te.bi, te.ti, te.s0i]]   # [n, 7]
+        out = np.full((state.shape[0], state.shape[2]), -1, np.int8)
+        for a in range(rows.shape[0]):
+            out[(key == rows[a][None, :, None]).all(axis=1)] = a
+        return out
 
     spawn_log = []          # roads of cars spawned in the current tick
     in_spawn = [False]
@@ -90,6 +113,8 @@ def run(name, sc, mods):
     def logged_add_car(road, car, *a):
         if in_spawn[0]:
             spawn_log.append(int(road))
+            rows = te.archetypes[:, arch_cols[1:]]
+            spawn_arch_log.append(int(np.argmax((rows == np.asarray(car)[arch_cols[1:]][None, :]).all(axis=1))))
         return orig_add_car(road, car, *a)
 
     def snap_mid(state, leading, lastcar):
@@ -149,8 +174,9 @@ def run(name, sc, mods):
         leader_x = np.zeros((T + 1, R), np.float32)
         spawn_off = np.zeros(T + 1, np.int64)
         spawn_road = []
+        spawn_arch = []
         se = sc["state_every"]
-        st_ticks, st_x, st_v, st_w, mid_x, mid_v = [], [], [], [], [], []
+        st_ticks, st_x, st_v, st_w, st_a, mid_x, mid_v = [], [], [], [], [], [], []
         remi_ticks, remi_rew, cor = [], [], []
         trip_count = np.zeros(T + 1, np.int64)
 
@@ -168,6 +194,10 @@ def run(name, sc, mods):
                 st_x.append(x)
                 st_v.append(v)
                 st_w.append(w)
+                if sc.get("archetypes"):
+                    live = (x != 0) | (v != 0) | (w != 0)
+                    a = arch_of(env.state)
+                    st_a.append(np.where(a >= 0, a, 0).astype(np.int8))
 
         env.waiting[:] = 0
         record(0)
@@ -182,9 +212,11 @@ def run(name, sc, mods):
                 cur = np.zeros(Iq, np.int32)
             actions[t] = cur
             del spawn_log[:]
+            del spawn_arch_log[:]
             # the reference accepts any dtype here (bool from a3c, float64 from const0)
             _, _, d, _ = env.step(cur.copy())
             spawn_road.extend(spawn_log)
+            spawn_arch.extend(spawn_arch_log)
             spawn_off[t + 1] = len(spawn_road)
             done[t + 1] = bool(d)
             trip_count[t + 1] = len(env.trip_times)
@@ -207,6 +239,9 @@ def run(name, sc, mods):
         if se:
             out.update(state_ticks=np.asarray(st_ticks, np.int64), state_x=np.stack(st_x),
                        state_v=np.stack(st_v), state_w=np.stack(st_w))
+        if sc.get("archetypes"):
+            out.update(archetypes=te.archetypes.copy(), spawn_arch=np.asarray(spawn_arch, np.int32),
+                       state_a=np.stack(st_a))
         if sc["mid"]:
             out.update(mid_x=np.stack(mid_x), mid_v=np.stack(mid_v))
         out["scenario"] = np.array(json.dumps(sc))
@@ -216,6 +251,7 @@ def run(name, sc, mods):
         te.add_car = orig_add_car
         te.advance_finished_cars = orig_adv
         te.advance_hack = orig_hack
+        te.archetypes = keep_archetypes
 
 
 def live_planes(state, leading, lastcar, C, planes):

@@ -81,6 +81,20 @@ static inline float pow4_cr(float q) {
   return (float)(q2 * q2);
 }
 
+/* (v/v0)**delta for the other integer exponents an archetype may carry (traffic_env.py:38 fixes 4; a user row may
+ * not): binary exponentiation in binary64 - result = 1, base = q; while n: if n odd result *= base; base *= base;
+ * n >>= 1 - rounded once to binary32.  For n = 4 that is (q*q)*(q*q), i.e. pow4_cr.  The HIP side runs the same
+ * multiplies; exponents that are not integers in 1..8 are outside the shared contract (powf here, rejected there). */
+static inline float powi_cr(float q, int n) {
+  double result = 1.0, base = (double)q;
+  while (n) {
+    if (n & 1) result *= base;
+    base *= base;
+    n >>= 1;
+  }
+  return (float)result;
+}
+
 /*
  * traffic_env.py:50-62  sim(r, ld, me): IDM over the slot range me = [lo+1 .. hi], ld = [lo .. hi-1]
  * of road e.  All temporaries are formed from the OLD values (NumPy evaluates whole arrays
@@ -98,7 +112,9 @@ static void sim(const orc_cfg *c, orc_env *v, int e, int lo, int hi, float *nx, 
     const float s = ST(v, c, e, XI, j - 1) - ST(v, c, e, XI, j) - ST(v, c, e, LI, j - 1);
     const float q = vel / ST(v, c, e, V0I, j);
     const float delta = ST(v, c, e, DELTAI, j);
-    const float qd = (delta == 4.0f) ? pow4_cr(q) : powf(q, delta);
+    const float qd = (delta == 4.0f) ? pow4_cr(q)
+                     : (delta >= 1.0f && delta <= 8.0f && delta == (float)(int)delta) ? powi_cr(q, (int)delta)
+                                                                                     : powf(q, delta);
     const float u = s_star / (s + c->eps);
     const float dv = ST(v, c, e, AI, j) * ((1.0f - qd) - u * u);
     const float dvr = dv * r;
@@ -276,9 +292,25 @@ void orc_reset(const orc_cfg *c, orc_env *v, const int32_t *phase_init) {
  * traffic_env.py:224-248  _step for ONE env.  `action` int32[I]; `spawn_roads` lists the entry
  * road of every car add_new_cars (:274-283) would create this tick, in order.  Returns overflowed.
  */
+int orc_step_arch(const orc_cfg *c, const int32_t *dests, const int32_t *phases, const int32_t *nexts,
+                  orc_env *v, const int32_t *action, const int32_t *spawn_roads, int n_spawn,
+                  float tick, float *trip_times, int64_t *n_trips, int64_t trip_cap, int64_t *updates,
+                  const float *archetypes, const int32_t *spawn_arch);
+
 int orc_step(const orc_cfg *c, const int32_t *dests, const int32_t *phases, const int32_t *nexts,
              orc_env *v, const int32_t *action, const int32_t *spawn_roads, int n_spawn,
              float tick, float *trip_times, int64_t *n_trips, int64_t trip_cap, int64_t *updates) {
+  return orc_step_arch(c, dests, phases, nexts, v, action, spawn_roads, n_spawn, tick, trip_times, n_trips, trip_cap,
+                       updates, NULL, NULL);
+}
+
+/* ... with the reference's `archetypes` table (traffic_env.py:35-43: float32[n][10], any number of rows) and, per
+ * spawned car, the row add_new_cars drew for it (`archetypes[random.randint(archetypes.shape[0])]`, :164); NULL
+ * table = the single archetype of the config. */
+int orc_step_arch(const orc_cfg *c, const int32_t *dests, const int32_t *phases, const int32_t *nexts,
+                  orc_env *v, const int32_t *action, const int32_t *spawn_roads, int n_spawn,
+                  float tick, float *trip_times, int64_t *n_trips, int64_t trip_cap, int64_t *updates,
+                  const float *archetypes, const int32_t *spawn_arch) {
   int32_t *passed = v->obs, *cur = v->obs + 2 * c->r, *elapsed = cur + c->I;
   for (int i = 0; i < c->I; ++i) {
     int change;
@@ -297,7 +329,7 @@ int orc_step(const orc_cfg *c, const int32_t *dests, const int32_t *phases, cons
   int overflowed = 0;
   float car[NPARAMS];
   for (int k = 0; k < n_spawn; ++k) {
-    memcpy(car, c->archetype, sizeof car);
+    memcpy(car, archetypes ? archetypes + (size_t)(spawn_arch ? spawn_arch[k] : 0) * NPARAMS : c->archetype, sizeof car);
     car[WI] = tick;
     overflowed = add_car(c, spawn_roads[k], car, v, dests) || overflowed;
   }
@@ -335,11 +367,27 @@ void orc_reset_batch(const orc_cfg *c, const orc_bufs *b, const int32_t *phase_i
 
 /* action [E][I]; spawn_off [E+1] into spawn_roads; ticks float32[E]; done u8[E] out.
  * trip buffers optional: trip_times [E][trip_cap], n_trips [E]. */
+void orc_step_batch_arch(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
+                         const int32_t *nexts, const orc_bufs *b, const int32_t *action,
+                         const int64_t *spawn_off, const int32_t *spawn_roads, const float *ticks,
+                         float *trip_times, int64_t *n_trips, int64_t trip_cap, int nthreads,
+                         int64_t *updates, const float *archetypes, const int32_t *spawn_arch);
+
 void orc_step_batch(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
                     const int32_t *nexts, const orc_bufs *b, const int32_t *action,
                     const int64_t *spawn_off, const int32_t *spawn_roads, const float *ticks,
                     float *trip_times, int64_t *n_trips, int64_t trip_cap, int nthreads,
                     int64_t *updates) {
+  orc_step_batch_arch(c, dests, phases, nexts, b, action, spawn_off, spawn_roads, ticks, trip_times, n_trips, trip_cap,
+                      nthreads, updates, NULL, NULL);
+}
+
+/* archetypes float32[n][10] + spawn_arch int32[] parallel to spawn_roads (both NULL: the config's archetype) */
+void orc_step_batch_arch(const orc_cfg *c, const int32_t *dests, const int32_t *phases,
+                         const int32_t *nexts, const orc_bufs *b, const int32_t *action,
+                         const int64_t *spawn_off, const int32_t *spawn_roads, const float *ticks,
+                         float *trip_times, int64_t *n_trips, int64_t trip_cap, int nthreads,
+                         int64_t *updates, const float *archetypes, const int32_t *spawn_arch) {
   int64_t total = 0;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1) reduction(+ : total)
@@ -347,10 +395,11 @@ void orc_step_batch(const orc_cfg *c, const int32_t *dests, const int32_t *phase
   for (int k = 0; k < c->E; ++k) {
     orc_env v = env_view(c, b, k);
     int64_t u = 0;
-    b->done[k] = (uint8_t)orc_step(c, dests, phases, nexts, &v, action + (size_t)k * c->I,
-                                   spawn_roads + spawn_off[k], (int)(spawn_off[k + 1] - spawn_off[k]),
-                                   ticks[k], trip_times ? trip_times + (size_t)k * trip_cap : NULL,
-                                   n_trips ? n_trips + k : NULL, trip_cap, &u);
+    b->done[k] = (uint8_t)orc_step_arch(c, dests, phases, nexts, &v, action + (size_t)k * c->I,
+                                        spawn_roads + spawn_off[k], (int)(spawn_off[k + 1] - spawn_off[k]),
+                                        ticks[k], trip_times ? trip_times + (size_t)k * trip_cap : NULL,
+                                        n_trips ? n_trips + k : NULL, trip_cap, &u, archetypes,
+                                        spawn_arch ? spawn_arch + spawn_off[k] : NULL);
     total += u;
   }
   if (updates) *updates += total;

@@ -154,9 +154,11 @@ class OracleEnv(object):
         self.n_trips[:] = 0
         return self.obs
 
-    def step(self, action, spawn_roads=None, nthreads=1):
+    def step(self, action, spawn_roads=None, nthreads=1, spawn_arch=None, archetypes=None):
         """action int[E][I] (or [I], broadcast); spawn_roads: list (len E) of int sequences, or a
-        (spawn_off int64[E+1], roads int32[]) CSR pair, or None."""
+        (spawn_off int64[E+1], roads int32[]) CSR pair, or None.  archetypes float32 [n, 10] (the reference's
+        `archetypes` table, traffic_env.py:35-43) with spawn_arch - list (len E) of the row drawn for every spawned car,
+        parallel to spawn_roads - for runs with more than the config's single archetype."""
         act = np.ascontiguousarray(np.broadcast_to(np.asarray(action, np.int32), (self.E, self.I)))
         if spawn_roads is None:
             off = np.zeros(self.E + 1, np.int64)
@@ -174,10 +176,17 @@ class OracleEnv(object):
             roads = np.zeros(max(1, int(off[-1])), np.int32)
             for k, s in enumerate(spawn_roads):
                 roads[off[k]:off[k + 1]] = s
-        lib().orc_step_batch(C.byref(self.cfg), _p(self.dest), _p(self.phases), _p(self.nexts),
-                             C.byref(self.bufs), _p(act), _p(off), _p(roads), _p(self.steps),
-                             _p(self.trip_times), _p(self.n_trips), C.c_int64(self.trip_cap),
-                             C.c_int(int(nthreads)), C.byref(self._updates))
+        arch_tab = arch_ids = None
+        if archetypes is not None:
+            arch_tab = np.ascontiguousarray(archetypes, np.float32).reshape(-1, NPARAMS)
+            arch_ids = np.zeros(max(1, int(off[-1])), np.int32)
+            if spawn_arch is not None:
+                for k, s in enumerate(spawn_arch):
+                    arch_ids[off[k]:off[k + 1]] = s
+        lib().orc_step_batch_arch(C.byref(self.cfg), _p(self.dest), _p(self.phases), _p(self.nexts),
+                                  C.byref(self.bufs), _p(act), _p(off), _p(roads), _p(self.steps),
+                                  _p(self.trip_times), _p(self.n_trips), C.c_int64(self.trip_cap),
+                                  C.c_int(int(nthreads)), C.byref(self._updates), _p(arch_tab), _p(arch_ids))
         self.steps += np.float32(1)
         return self.obs, self.rewards, self.done
 
@@ -210,20 +219,34 @@ class OracleEnv(object):
         return np.transpose(flat.reshape(self.E, 4, self.m, self.n), (0, 2, 3, 1))
 
     # ---- state import/export in (x, v, w) planes, the layout the HIP path and fixtures use ----
-    def load_planes(self, k, x, v, w, leading, lastcar):
+    def load_planes(self, k, x, v, w, leading, lastcar, arch=None, archetypes=None):
         """Set env k from [R, C] planes: live slots become archetype cars carrying (x, v, w); the
-        fake-leader slot gets all-zero params and the given x (traffic_env.py:262-263,133)."""
+        fake-leader slot gets all-zero params and the given x (traffic_env.py:262-263,133).  arch int [R, C] +
+        archetypes float32 [n, 10]: the table row each live slot's car was copied from (default: the config's)."""
         self.leading[k] = leading
         self.lastcar[k] = lastcar
         live = live_mask(self.leading[k], self.lastcar[k], self.C)
         st = self.state[k]
-        arch = np.asarray(self.cfg.archetype[:], np.float32)
-        st[:] = arch[None, :, None] * live[:, None, :].astype(np.float32)
+        if arch is None:
+            rows = np.asarray(self.cfg.archetype[:], np.float32)[None, :, None]
+        else:
+            rows = np.transpose(np.asarray(archetypes, np.float32)[np.asarray(arch, np.int64)], (0, 2, 1))   # [R, 10, C]
+        st[:] = rows * live[:, None, :].astype(np.float32)
         st[:, XI, :] = np.where(live, x, 0)
         st[:, VI, :] = np.where(live, v, 0)
         st[:, WI, :] = np.where(live, w, 0)
         rows = np.arange(self.R)
         st[rows, XI, self.leading[k]] = np.asarray(x)[rows, self.leading[k]]
+
+    def arch_plane(self, k, archetypes):
+        """int8 [R, C]: row of `archetypes` each slot's car equals in everything but x, v, w (0 where none does)."""
+        cols = [LI, AI, DELTAI, V0I, BI, TI, S0I]
+        key = self.state[k][:, cols, :]
+        tab = np.asarray(archetypes, np.float32)[:, cols]
+        out = np.zeros((self.R, self.C), np.int8)
+        for a in range(tab.shape[0]):
+            out[(key == tab[a][None, :, None]).all(axis=1)] = a
+        return out
 
     def planes(self, k=0):
         """(x, v, w) [R, C] copies with dead slots zeroed (leader slot keeps its x)."""

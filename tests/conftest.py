@@ -25,8 +25,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (HIP kernels run)")
 
 
-def golden_names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+def golden_names(archetypes=False):
+    """Captured reference runs.  archetypes=False: the runs on the reference's single default archetype (what the
+    generic parity tests replay); True: the runs with several archetype rows; None: all."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    if archetypes is None:
+        return names
+    return [n for n in names if ("archetypes" in n) == bool(archetypes)]
 
 
 class Golden(object):
@@ -49,6 +54,23 @@ class Golden(object):
     def spawns(self, t):
         off = self["spawn_off"]
         return self["spawn_road"][off[t]:off[t + 1]]
+
+    @property
+    def archetypes(self):
+        """The reference's `archetypes` table of the run (float32 [n, 10], the spawn-tick column zeroed), or None
+        for runs on its single default row."""
+        if "archetypes" not in self:
+            return None
+        a = self["archetypes"].copy()
+        a[:, 9] = 0                 # (the reference writes car[wi] = tick through a VIEW of the row: not a parameter)
+        return a
+
+    def spawn_archs(self, t):
+        """Table row drawn for every car spawned at tick t (parallel to spawns(t)); None without a table."""
+        if "archetypes" not in self:
+            return None
+        off = self["spawn_off"]
+        return self["spawn_arch"][off[t]:off[t + 1]]
 
 
 @pytest.fixture(scope="session")

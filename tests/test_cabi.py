@@ -53,7 +53,7 @@ def test_struct_layouts_match_header():
             decl = decl.strip()
             if not decl:
                 continue
-            out += [n.strip().lstrip("*") for n in re.sub(r"^[a-z0-9_]+\s+", "", decl).split(",")]
+            out += [re.sub(r"\[.*", "", n.strip().lstrip("*")) for n in re.sub(r"^[a-z0-9_]+\s+", "", decl).split(",")]
         return out
     assert fields("tfx_config") == [f[0] for f in _native.TfxConfig._fields_]
     assert fields("tfx_buffers") == [f[0] for f in _native.TfxBuffers._fields_]

@@ -66,8 +66,21 @@ def test_gym_surface_reproduces_reference_run(name, golden_cache):
             n = int(g["trip_count"][120])
             assert len(env.trip_times) == n
             assert np.array_equal(np.asarray(env.trip_times, np.float64), g["trip_times"][:n])
+        # env.state in the reference's shape (traffic_env.py:364): [R, 10, C], wi / li at the reference's indices,
+        # a car's seven constants on its slot, zeros on the fake leader's
+        from gym_traffic.envs import traffic_env as te
         st = env.state.numpy()
-        assert st.shape == (env.graph.roads, 3, sc["C"])
+        assert st.shape == (env.graph.roads, 10, sc["C"]) and env.state.shape == st.shape
+        live = live_mask(np.asarray(env.leading), np.asarray(env.lastcar), sc["C"])
+        assert live.any()
+        for col, val in ((te.li, 4), (te.ai, 3), (te.deltai, 4), (te.v0i, 13.89), (te.bi, 6), (te.ti, 2), (te.s0i, 1)):
+            assert np.all(st[:, col, :][live] == np.float32(val)) and np.all(st[:, col, :][~live] == 0)
+        rows = np.arange(env.graph.roads)
+        assert np.all(st[rows, te.vi, np.asarray(env.leading)] == 0)
+        if "state_x" in g and sc["state_every"] == 1:
+            # (free-running for 120 ticks: within the drift the float contract allows)
+            assert np.allclose(st[:, te.xi, :][live], g["state_x"][120][live], rtol=1e-4, atol=1e-3)
+            assert np.array_equal(st[:, te.wi, :][live], g["state_w"][120][live])
     finally:
         update_flags(poisson=True, rate=0.5, local_cars_per_sec=0.12, entry='all', learn_switch=False, mode='train')
 

@@ -14,7 +14,7 @@ from gym_traffic.spawner import SpawnSchedule, counts_from_roads
 from gym_traffic import workload as wl
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(None))
 def test_gridroad_tables_and_spawn_schedule_match_reference(name, golden_cache):
     g = golden_cache(name)
     sc = g.sc
@@ -29,11 +29,15 @@ def test_gridroad_tables_and_spawn_schedule_match_reference(name, golden_cache):
     # reset_entrypoints: cars_per_sec = local * m * open sides (traffic_env.py:394)
     cps = sc["lcps"] * sc["m"] * (4 - bin(spec).count("1"))
     assert cps == float(g["cars_per_sec"])
-    s = SpawnSchedule(np.random.RandomState(sc["seed"]), sc["poisson"], gr.entrypoints, lambda: (cps, sc["rate"]))
+    n_arch = 1 if g.archetypes is None else len(g.archetypes)
+    s = SpawnSchedule(np.random.RandomState(sc["seed"]), sc["poisson"], gr.entrypoints, lambda: (cps, sc["rate"]),
+                      n_archetypes=n_arch)
     n = 0
     for t in range(sc["T"]):
         got = s.next_tick()
         assert got == g.spawns(t).tolist(), (name, t)
+        if n_arch > 1:      # ... and the archetype row add_new_cars drew for each of them (traffic_env.py:164)
+            assert s.rows == g.spawn_archs(t).tolist(), (name, t)
         n += len(got)
     assert n == int(g["generated_cars"])
 

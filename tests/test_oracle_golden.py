@@ -28,6 +28,12 @@ def make_env(g, n_envs=1):
                      validate=sc["mode"] == "validate")
 
 
+def step(env, g, t):
+    """One oracle tick with the fixture's inputs of tick t (incl. the archetype row of every spawned car)."""
+    sa = g.spawn_archs(t)
+    return env.step(g["actions"][t], [g.spawns(t)], spawn_arch=None if sa is None else [sa], archetypes=g.archetypes)
+
+
 def ints_equal(env, obs, rew, done, g, k):
     return [n for n, a, b in (
         ("leading", env.leading[0], g["leading"][k]), ("lastcar", env.lastcar[0], g["lastcar"][k]),
@@ -36,14 +42,14 @@ def ints_equal(env, obs, rew, done, g, k):
         ("passed_dst", env.passed_dst[0], g["passed_dst"][k])) if not np.array_equal(a, b)]
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(None))
 def test_free_running_integers(name, golden_cache):
     g = golden_cache(name)
     env = make_env(g)
     env.reset(g["init_phase"])
     ri = 0
     for t in range(min(FREE_TICKS, g.sc["T"])):
-        obs, rew, done = env.step(g["actions"][t], [g.spawns(t)])
+        obs, rew, done = step(env, g, t)
         k = t + 1
         assert ints_equal(env, obs, rew, done, g, k) == [], (name, k)
         if g.sc["remi_every"] and k % g.sc["remi_every"] == 0:
@@ -53,7 +59,7 @@ def test_free_running_integers(name, golden_cache):
     assert ri > 0
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if "ints" not in n])
+@pytest.mark.parametrize("name", [n for n in golden_names(None) if "ints" not in n])
 def test_teacher_forced_every_tick(name, golden_cache):
     """From every tick whose car states the fixture carries (all of them for the 2x2 / 3x3 runs, every 10th for
     g4x4_cfg1, ticks 20 j and 20 j + 1 for g8x8_c130): integers of tick t+1 exact, floats within TF_ULP wherever the
@@ -68,7 +74,8 @@ def test_teacher_forced_every_tick(name, golden_cache):
         if t >= sc["T"]:
             continue
         i = at[t]
-        env.load_planes(0, g["state_x"][i], g["state_v"][i], g["state_w"][i], g["leading"][t], g["lastcar"][t])
+        env.load_planes(0, g["state_x"][i], g["state_v"][i], g["state_w"][i], g["leading"][t], g["lastcar"][t],
+                        arch=g["state_a"][i] if g.archetypes is not None else None, archetypes=g.archetypes)
         env.obs[0] = g["obs"][t]
         env.rewards[0] = g["rewards"][t]
         env.waiting[0] = g["waiting"][t]
@@ -77,7 +84,7 @@ def test_teacher_forced_every_tick(name, golden_cache):
             env.remi_reward()          # the capture called remi_reward() after recording tick t
         env.steps[0] = t
         wrapped_seen += int((g["leading"][t] > g["lastcar"][t]).sum())
-        obs, rew, done = env.step(g["actions"][t], [g.spawns(t)])
+        obs, rew, done = step(env, g, t)
         k = t + 1
         assert ints_equal(env, obs, rew, done, g, k) == [], (name, k)
         assert np.array_equal(env.x[0][rows, env.leading[0]], g["leader_x"][k])
@@ -89,6 +96,8 @@ def test_teacher_forced_every_tick(name, golden_cache):
             assert ulp_diff(x[live], g["state_x"][at[k]][live]).max() <= TF_ULP
             assert ulp_diff(v[live], g["state_v"][at[k]][live]).max() <= TF_ULP
             assert np.array_equal(w[live], g["state_w"][at[k]][live])
+            if g.archetypes is not None:   # every car still carries the row it was spawned from, through every handoff
+                assert np.array_equal(env.arch_plane(0, g.archetypes)[live], g["state_a"][at[k]][live])
             floats_checked += int(live.sum())
     if name == "g3x3_default":
         assert wrapped_seen > 100      # the wrapped-ring branch (traffic_env.py:202-212) is exercised

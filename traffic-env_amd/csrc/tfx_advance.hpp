@@ -188,7 +188,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
           // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed; <= 2 pops here)
           const float cw = !d.w ? 0.0f : (TL ? d.outw[ocol_of(d, env, x) + (size_t)j * 64] : d.w[(size_t)idx * d.C + ps]);
           if (d.trip_times && t < d.trip_cap)
-            d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
+            d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - side_tick(d, cw)) / 2.0f;
           ++t;
           ps = wrap1(ps + 1, d.C);
         }

@@ -29,7 +29,8 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int k_e = rec_kpop(rc.x);
   float tail_x = __int_as_float(rc.z);
   const int ld_post = ring_adv(ld, k_e, C);
-  int m = rc.w - k_e;  // cars physically on the road after the move
+  int m = rec_ntot(rc.w) - k_e;  // cars physically on the road after the move
+  int ta = rec_taila(rc.w);      // heterogeneous cars: table row of the tail (whose length and gap a push queues behind)
 
   int ovf = 0;
   const int p = d.pred[e];
@@ -49,11 +50,16 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
         const float2 car = d.outb[pcol + (size_t)j * 64];
         const float xc = car.x - d.length;  // state[e,xi,newlead] -= length (:130)
         const int pos = wrap1(lc + 1, C);
-        const float start = (lc != ld_seen) ? (tail_x - d.car_l) - d.car_s0 : INFINITY;
+        const float tl = d.het ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = d.het ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
+        const float start = (lc != ld_seen) ? (tail_x - tl) - ts0 : INFINITY;
         if (pos != ld_seen) {
           const float xv = (start < xc) ? start : xc;
           d.xv[ecol + (size_t)m * 64] = make_float2(xv, car.y);
-          if (d.w) d.w[ecol + (size_t)m * 64] = d.outw[pcol + (size_t)j * 64];
+          if (d.w) {
+            const float cw = d.outw[pcol + (size_t)j * 64];
+            d.w[ecol + (size_t)m * 64] = cw;
+            ta = side_arch(cw);
+          }
           ++m;
           lc = pos;
           tail_x = xv;
@@ -66,6 +72,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   }
   if (k_e > 0) d.leading[id] = ld_post;
   d.tailx[id] = tail_x;
+  if (d.het) d.taila[id] = ta;
   return ovf;
 }
 
@@ -100,7 +107,10 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
 
   // what update_lights and add_car call the tail of a road is tracked in tailx from here on: the last car the
   // move kernel processed (after a two-tick pass the rows themselves are already a tick ahead), then every push
-  for (int e = 0; e < d.R; ++e) d.tailx[env * d.R + e] = __int_as_float(d.rec[env * d.R + e].z);
+  for (int e = 0; e < d.R; ++e) {
+    d.tailx[env * d.R + e] = __int_as_float(d.rec[env * d.R + e].z);
+    if (d.het) d.taila[env * d.R + e] = rec_taila(d.rec[env * d.R + e].w);
+  }
   // row k of a road's column, counted from its first live row
   auto rowb = [&](int idq, int k) { return tpos(d, idq, k + rec_hb(d.rec[idq].y)); };
 
@@ -125,7 +135,9 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int phys = ring_count(ldn, lcn, C) - pending;          // survivors + cars pushed so far
     const int base = (pending > 0 && rec_unc(rn.y)) ? pending : 0;  // rows the pending cars occupy
     const int pos = wrap1(lcn + 1, C);
-    const float start = (lcn != ldn) ? (d.tailx[idn] - d.car_l) - d.car_s0 : INFINITY;
+    const int ta = d.het ? d.taila[idn] : 0;
+    const float tl = d.het ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = d.het ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
+    const float start = (lcn != ldn) ? (d.tailx[idn] - tl) - ts0 : INFINITY;
     if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
     if (pos != ldn) {
       const float xv = (start < car.x) ? start : car.x;
@@ -133,6 +145,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
       if (d.w) d.w[rowb(idn, base + phys)] = cw;
       d.lastcar[idn] = pos;
       d.tailx[idn] = xv;
+      if (d.het) d.taila[idn] = side_arch(cw);
     } else {
       if (nr < d.r) rew[nr % d.I] -= d.ovf_pen;
       overflowed = 1;
@@ -143,7 +156,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
   auto trip = [&](float cw) {
     if (d.validate && d.n_trips) {
       const int t = d.n_trips[env];
-      if (d.trip_times && t < d.trip_cap) d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - cw) / 2.0f;
+      if (d.trip_times && t < d.trip_cap) d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - side_tick(d, cw)) / 2.0f;
       d.n_trips[env] = t + 1;
     }
   };

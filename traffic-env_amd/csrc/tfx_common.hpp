@@ -72,6 +72,13 @@ struct Dev {
   const int *spawn;
   int spawn_mode, spawn_period;
   long spawn_stride;
+  // heterogeneous cars (tfx_config.n_archetypes): every car's side word w holds 8 * spawn tick + table row
+  int het;
+  const float *arch_tab;         // [TFX_MAX_ARCH][ARCH_W]: l, a, v0, T, s0, 2 sqrt(a b), delta, spawn speed
+  int *taila;                    // per road: table row of its last car (next to tailx)
+  const uint8_t *spawn_arch;     // rows of the cars the count buffer adds: [tick][E][n_entry][spawn_arch_S]
+  int spawn_arch_S;
+  long spawn_arch_stride;
 };
 
 // The vehicle-update counter is spread over VEH_SLOTS words, one cache line apart: every wavefront
@@ -113,6 +120,43 @@ __device__ __forceinline__ void idm_step(const Dev &d, float x, float v, float x
   const float qd = pow4_cr(q);
   const float u = s_star / (s + d.eps);
   const float dv = d.car_a * ((1.0f - qd) - u * u);
+  const float dvr = dv * d.rate;
+  const float dx = d.rate * v + (0.5f * dvr) * d.rate;
+  xn = x + (dx > 0.0f ? dx : 0.0f * dx);
+  vn = np_max0(v + dvr);
+}
+
+// ---- heterogeneous cars ---------------------------------------------------------------------------------
+constexpr int ARCH_W = 8;
+enum { AR_L = 0, AR_A, AR_V0, AR_T, AR_S0, AR_2SAB, AR_DELTA, AR_V };
+__device__ __forceinline__ int side_arch(float wa) { return ((int)wa) & (TFX_MAX_ARCH - 1); }
+__device__ __forceinline__ float side_tick(const Dev &d, float wa) { return d.het ? floorf(wa * 0.125f) : wa; }
+__device__ __forceinline__ float side_pack(float tick, int row) { return tick * 8.0f + (float)row; }
+
+// (v/v0)**delta for an integer delta in 1..8: oracle/idm_oracle.c powi_cr, multiply for multiply
+__device__ __forceinline__ float powi_cr(float q, int n) {
+  double result = 1.0, base = (double)q;
+  while (n) {
+    if (n & 1) result *= base;
+    base *= base;
+    n >>= 1;
+  }
+  return (float)result;
+}
+
+// sim (traffic_env.py:50-62) for one car with its OWN parameters (row `me` of the table) behind a leader of
+// length ll: the literal expression order of idm_step, IEEE divisions throughout
+__device__ __forceinline__ void idm_step_het(const Dev &d, const float *me, float x, float v, float xl, float vl, float ll,
+                                             float &xn, float &vn) {
+  const float t_gap = v * me[AR_T];
+  const float appr = v * (v - vl);
+  const float s_star = me[AR_S0] + np_max0(t_gap + appr / me[AR_2SAB]);
+  const float s = (xl - x) - ll;
+  const float q = v / me[AR_V0];
+  const int delta = (int)me[AR_DELTA];
+  const float qd = delta == 4 ? pow4_cr(q) : powi_cr(q, delta);
+  const float u = s_star / (s + d.eps);
+  const float dv = me[AR_A] * ((1.0f - qd) - u * u);
   const float dvr = dv * d.rate;
   const float dx = d.rate * v + (0.5f * dvr) * d.rate;
   xn = x + (dx > 0.0f ? dx : 0.0f * dx);
@@ -273,6 +317,9 @@ __device__ __forceinline__ bool rec_unc(int ry) { return (ry >> 30) & 1; }
 // call reads past them and writes the column compacted again (tfx_move_tt.hpp).
 __device__ __forceinline__ int rec_hb(int ry) { return (ry >> 28) & 3; }
 __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
+// rec.w: cars on the road during the move (incl. this tick's arrivals) | table row of the last of them << 16
+__device__ __forceinline__ int rec_ntot(int rw) { return rw & 0xffff; }
+__device__ __forceinline__ int rec_taila(int rw) { return rw >> 16; }
 
 // The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car
 // would itself be popped again downstream this tick, or (c) a full ring pops two or more cars

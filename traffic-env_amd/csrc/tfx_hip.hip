@@ -76,6 +76,8 @@ struct tfx_handle_s {
   hipStream_t split_stream = nullptr;
   hipEvent_t split_fork = nullptr, split_join = nullptr;
   int *tick2 = nullptr;       // clock words of the second half (tickA, tickB), risk word
+  bool het = false;           // heterogeneous cars (tfx_config.n_archetypes)
+  float *dev_arch = nullptr;  // the archetype table on the device
   long long split_ticks = 0;  // ticks that ran split since tfx_create
   int pairs = 1;              // two-tick passes in tfx_step (tfx_move_tt.hpp): TFX_PAIRS=0 never, 2 at any size
   std::vector<int32_t> h_dest, h_phases, h_nexts, h_pred, h_entry, h_entry_idx, h_road_slot, h_slot_road;
@@ -257,6 +259,10 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   // (260) 0.075 -> 0.028, cfg1 x 256 (320) 0.023 -> 0.016, cfg4 x 4 (1040 tiles of 128 rows) 0.102 ->
   // 0.083; no gain at cfg2 x 64 (1088) and a loss at cfg1 x 1024 (1280): there the redundant road
   // prologues outweigh the shorter walks
+  if (h->het) {  // heterogeneous cars: the one kernel that reads a car's parameters from its table row
+    h->step_kernel = "k_move_t";
+    return go(k_move_t<4, 3, true, true>);
+  }
   const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
   if (pvar == 90 || (tiles <= split_below && pvar == 0)) {
     auto gs = [&](auto kern) {
@@ -418,7 +424,7 @@ int res_configure(tfx_handle h) {
 // the resident kernel serves a call when the envs fit and trip times are not recorded (their order is
 // the serial loop's)
 bool res_usable(tfx_handle h, int n_ticks) {
-  return h->res_epb > 0 && !h->d.validate && n_ticks >= h->res_min_ticks;
+  return h->res_epb > 0 && !h->d.validate && !h->het && n_ticks >= h->res_min_ticks;
 }
 
 int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi = 0, float *aobs = nullptr,
@@ -798,7 +804,22 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (cfg->planes != 2 && cfg->planes != 3) return fail(TFX_EINVAL, "planes must be 2 (x,v) or 3 (x,v,w)");
   if (cfg->validate && cfg->planes != 3) return fail(TFX_EINVAL, "validate mode needs planes = 3 (spawn tick w)");
   if (cfg->layout != 0 && cfg->layout != 1) return fail(TFX_EINVAL, "layout must be 0 (ring) or 1 (transposed)");
-  if (cfg->car_delta != 4.0f) return fail(TFX_EINVAL, "only delta = 4 (the reference's archetype) is supported");
+  const int n_arch = cfg->n_archetypes <= 1 ? 1 : cfg->n_archetypes;
+  if (n_arch > TFX_MAX_ARCH) return fail(TFX_EINVAL, "at most %d archetype rows", TFX_MAX_ARCH);
+  bool het = n_arch > 1;
+  float arch_rows[TFX_MAX_ARCH][8] = {};
+  for (int a = 0; a < n_arch; ++a) {
+    const float single[8] = {cfg->car_v, cfg->car_l, cfg->car_a, cfg->car_delta, cfg->car_v0, cfg->car_b, cfg->car_T, cfg->car_s0};
+    memcpy(arch_rows[a], cfg->n_archetypes >= 1 ? cfg->arch[a] : single, sizeof single);
+    const float delta = arch_rows[a][3];
+    if (!(delta >= 1.0f && delta <= 8.0f) || delta != (float)(int)delta)
+      return fail(TFX_EINVAL, "archetype %d: delta = %g - only integers 1..8 have a bit-exact power (oracle powi_cr)", a, delta);
+    if (delta != 4.0f) het = true;
+    if (!(arch_rows[a][2] > 0.0f) || !(arch_rows[a][5] > 0.0f) || !(arch_rows[a][4] > 0.0f))
+      return fail(TFX_EINVAL, "archetype %d: a, b and v0 must be > 0", a);
+  }
+  if (het && (cfg->layout != 1 || cfg->planes != 3))
+    return fail(TFX_EINVAL, "heterogeneous cars (several archetypes, or delta != 4) need layout = 1 and planes = 3");
   if (!(cfg->length > 0.0f) || !(cfg->rate > 0.0f)) return fail(TFX_EINVAL, "length and rate must be > 0");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
@@ -806,6 +827,13 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   tfx_handle_s *h = new (std::nothrow) tfx_handle_s();
   if (!h) return fail(TFX_ENOMEM, "out of host memory");
   h->cfg = *cfg;
+  h->het = het;
+  if (!het && cfg->n_archetypes == 1) {  // one ordinary row given through the table: it IS the archetype
+    h->cfg.car_v = arch_rows[0][0]; h->cfg.car_l = arch_rows[0][1]; h->cfg.car_a = arch_rows[0][2];
+    h->cfg.car_delta = arch_rows[0][3]; h->cfg.car_v0 = arch_rows[0][4]; h->cfg.car_b = arch_rows[0][5];
+    h->cfg.car_T = arch_rows[0][6]; h->cfg.car_s0 = arch_rows[0][7];
+    cfg = &h->cfg;
+  }
   build_tables(h);
   build_slots(h);
   if (const char *mv = getenv("TFX_MOVE_VARIANT")) h->move_variant = atoi(mv);
@@ -887,6 +915,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_outb = off;  off = align_up(off + (d.layout == 1 ? n_opairs * sizeof(float2) : 0), 256);
   const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_opairs * sizeof(float) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + ER * sizeof(float), 256);
+  const size_t o_taila = off; off = align_up(off + (het ? ER * sizeof(int) : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 128, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {
@@ -909,6 +938,25 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.outb = (float2 *)(base + o_outb);
   d.outw = (float *)(base + o_outw);
   d.leadx = (float *)(base + o_lead);
+  d.het = het ? 1 : 0;
+  d.taila = (int *)(base + o_taila);
+  if (het) {
+    float tab[TFX_MAX_ARCH][ARCH_W] = {};
+    for (int a = 0; a < n_arch; ++a) {
+      const float *r = arch_rows[a];  // v, l, a, delta, v0, b, T, s0
+      tab[a][AR_L] = r[1]; tab[a][AR_A] = r[2]; tab[a][AR_V0] = r[4]; tab[a][AR_T] = r[6]; tab[a][AR_S0] = r[7];
+      tab[a][AR_2SAB] = 2.0f * sqrtf(r[2] * r[5]);  // 2 * np.sqrt(a*b) (traffic_env.py:54)
+      tab[a][AR_DELTA] = r[3]; tab[a][AR_V] = r[0];
+    }
+    if (hipMalloc((void **)&h->dev_arch, sizeof tab) != hipSuccess ||
+        hipMemcpy(h->dev_arch, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(h->dev_tables);
+      (void)hipFree(h->dev_scratch);
+      delete h;
+      return fail(TFX_ENOMEM, "uploading the archetype table failed");
+    }
+    d.arch_tab = h->dev_arch;
+  }
   h->n_tpairs = n_tpairs;
   d.veh = (unsigned long long *)(base + o_veh);
   d.tickA = (int *)(base + o_misc + 16);
@@ -964,6 +1012,7 @@ int tfx_destroy(tfx_handle h) {
   if (h->dev_greedy) (void)hipFree(h->dev_greedy);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
   if (h->dev_scratch) (void)hipFree(h->dev_scratch);
+  if (h->dev_arch) (void)hipFree(h->dev_arch);
   delete h;
   return TFX_OK;
 }
@@ -1091,12 +1140,26 @@ int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t perio
   return TFX_OK;
 }
 
+int tfx_set_spawn_archetypes(tfx_handle h, const uint8_t *dev, int32_t per_road, int32_t per_tick) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (!h->het) return fail(TFX_ESTATE, "the handle has a single archetype");
+  if (dev && per_road < 1) return fail(TFX_EINVAL, "per_road must be >= 1");
+  Dev &d = h->d;
+  ++h->input_gen;
+  d.spawn_arch = dev;
+  d.spawn_arch_S = dev ? per_road : 0;
+  d.spawn_arch_stride = (dev && per_tick) ? (long)d.E * d.n_entry * per_road : 0;
+  return TFX_OK;
+}
+
 int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uint32_t *cdf, int32_t n_cdf) {
   if (int rc = check_handle(h, false)) return rc;
   if (!(cars_per_tick > 0.0)) return fail(TFX_EINVAL, "cars_per_tick must be > 0");
   if (!cdf || n_cdf < 1 || n_cdf > 65536) return fail(TFX_EINVAL, "gap table missing or too long");
   Dev &d = h->d;
   if (d.n_entry < 1) return fail(TFX_EINVAL, "no entry roads");
+  if (h->het) return fail(TFX_EINVAL, "the on-device Poisson stream draws no archetype rows: feed heterogeneous cars through "
+                                      "tfx_set_spawns + tfx_set_spawn_archetypes");
   ++h->input_gen;
   if (h->dev_ps) { (void)hipFree(h->dev_ps); h->dev_ps = nullptr; }
   const size_t n_counts = (size_t)d.E * d.n_entry;
@@ -1294,22 +1357,22 @@ int tfx_xv_pairs(tfx_handle h, int64_t *pairs) {
   return TFX_OK;
 }
 
-int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, void *stream) {
+int tfx_export_ring(tfx_handle h, float *ring_xv, float *ring_w, uint8_t *ring_a, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
   if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
   hipLaunchKernelGGL(k_export_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
-                     (hipStream_t)stream, h->d, reinterpret_cast<float2 *>(ring_xv), ring_w);
+                     (hipStream_t)stream, h->d, reinterpret_cast<float2 *>(ring_xv), ring_w, ring_a);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
-int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, void *stream) {
+int tfx_import_ring(tfx_handle h, const float *ring_xv, const float *ring_w, const uint8_t *ring_a, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (h->d.layout != 1) return fail(TFX_ESTATE, "the handle already uses the ring layout");
   if (!ring_xv) return fail(TFX_EINVAL, "ring_xv is null");
   hipLaunchKernelGGL(k_import_ring, dim3(grid_for((long)h->d.E * h->d.R, h->n_cu)), dim3(256), 0,
-                     (hipStream_t)stream, h->d, reinterpret_cast<const float2 *>(ring_xv), ring_w);
+                     (hipStream_t)stream, h->d, reinterpret_cast<const float2 *>(ring_xv), ring_w, ring_a);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }

@@ -52,13 +52,14 @@ __global__ void k_refresh(const Dev d) {
     } else {
       const int n = ring_count(d.leading[id], d.lastcar[id], d.C);
       d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1 + rec_hb(d.rec[id].y))].x : 0.0f;
+      if (d.het) d.taila[id] = (n > 0) ? side_arch(d.w[tpos(d, (int)id, n - 1)]) : 0;
     }
   }
 }
 
 // transposed layout <-> the reference's ring layout ([E][R][C] (x, v) by ring slot, the fake
 // leader's x in slot `leading`): what tfx_export_ring / tfx_import_ring run
-__global__ void k_export_ring(const Dev d, float2 *ring, float *ringw) {
+__global__ void k_export_ring(const Dev d, float2 *ring, float *ringw, uint8_t *ringa) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x) {
@@ -70,13 +71,17 @@ __global__ void k_export_ring(const Dev d, float2 *ring, float *ringw) {
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
       row[slot] = d.xv[tpos(d, (int)id, k + hb)];
-      if (ringw && d.w) ringw[(size_t)id * d.C + slot] = d.w[tpos(d, (int)id, k)];
+      if (d.w && (ringw || ringa)) {  // (heterogeneous cars: the side word is 8 * spawn tick + table row)
+        const float sw = d.w[tpos(d, (int)id, k)];
+        if (ringw) ringw[(size_t)id * d.C + slot] = side_tick(d, sw);
+        if (ringa) ringa[(size_t)id * d.C + slot] = d.het ? (uint8_t)side_arch(sw) : 0;
+      }
     }
     row[ld].x = d.leadx[id];
   }
 }
 
-__global__ void k_import_ring(const Dev d, const float2 *ring, const float *ringw) {
+__global__ void k_import_ring(const Dev d, const float2 *ring, const float *ringw, const uint8_t *ringa) {
   const long total = (long)d.E * d.R;
   for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total;
        id += (long)gridDim.x * blockDim.x) {
@@ -87,7 +92,10 @@ __global__ void k_import_ring(const Dev d, const float2 *ring, const float *ring
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
       d.xv[tpos(d, (int)id, k)] = row[slot];
-      if (ringw && d.w) d.w[tpos(d, (int)id, k)] = ringw[(size_t)id * d.C + slot];
+      if (d.w && (ringw || (d.het && ringa))) {
+        const float tk = ringw ? ringw[(size_t)id * d.C + slot] : 0.0f;
+        d.w[tpos(d, (int)id, k)] = d.het ? side_pack(tk, ringa ? (ringa[(size_t)id * d.C + slot] & (TFX_MAX_ARCH - 1)) : 0) : tk;
+      }
     }
     d.leadx[id] = row[ld].x;
     d.rec[id].y &= ~(3 << 28);  // the column starts at row 0 again

@@ -45,8 +45,17 @@ __device__ __forceinline__ size_t tpos(const Dev &d, int id, int k) {
 }
 
 // W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157)
-template <int P, int NT = 0, bool W = false>
+// HET (implies W): heterogeneous cars - the side word is 8 * spawn tick + the row of the archetype table the car was
+// spawned from (tfx_config.n_archetypes); a car's own row gives T, s0, a, b, v0, delta, its leader's row the length
+// the gap subtracts (sim reads ld[li], traffic_env.py:55); the table sits in LDS
+template <int P, int NT = 0, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
+  static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
+  __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
+  if (HET) {
+    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
@@ -89,6 +98,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     int shift = 0;                   // survivors move up by this many rows: the pops so far, or 0 once
                                      //   the road popped more than TFX_KP cars and stays uncompacted
     float tail_x = 0.0f;
+    int last_a = 0;  // HET: table row of the last car processed (the road's tail after the move)
     // wrapped ring: x, not v, is tested on slots 1..lastcar (:210) = the cars from index kq on
     const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
 
@@ -114,12 +124,19 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
     };
     auto step = [&](int k, float x, float v, float wv) {
       float xn, vn;
-      const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
-      if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
-      else idm_step(d, x, v, xprev, vprev, llv, xn, vn);
+      if (HET) {
+        last_a = side_arch(wv);
+        const float *me = s_arch + last_a * ARCH_W;
+        idm_step_het(d, me, x, v, xprev, vprev, llv, xn, vn);
+        llv = me[AR_L];
+      } else {
+        const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
+        if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+        else idm_step(d, x, v, xprev, vprev, llv, xn, vn);
+        llv = d.car_l;
+      }
       xprev = x;  // OLD state leads the next car (Jacobi)
       vprev = v;
-      llv = d.car_l;
       const bool pop = open && (xn > d.length);  // the while loop of :123
       open = pop;
       if (pop) {
@@ -178,8 +195,31 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         smax = o > smax ? o : smax;
       }
       smax = __builtin_amdgcn_readfirstlane(smax);
-      for (int s = 0; s < smax; ++s)
-        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick);  // w = spawn tick
+      if (HET) {
+        // add_car :97-114 car by car: each queues behind the road's tail at the moment it is created - the tail's
+        // OWN length and minimum gap - and brings the row add_new_cars drew for it (:164)
+        int lc = ring_adv(p.ld, n_old, C);
+        float tx = d.tailx[id];
+        int ta = d.taila[id];
+        const int ej = d.entry_idx[e];
+        const uint8_t *rows = (d.spawn_arch && d.spawn_mode == TFX_SPAWN_COUNTS && ej >= 0)
+                                  ? d.spawn_arch + (size_t)tidx * d.spawn_arch_stride +
+                                        ((size_t)env * d.n_entry + ej) * d.spawn_arch_S
+                                  : nullptr;
+        for (int s = 0; s < smax; ++s)
+          if (s < n_sp) {
+            const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
+            const float start = (lc != p.ld) ? (tx - s_arch[ta * ARCH_W + AR_L]) - s_arch[ta * ARCH_W + AR_S0] : INFINITY;
+            const float xs = (start < 0.0f) ? start : 0.0f;
+            step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack((float)tick, row));
+            lc = wrap1(lc + 1, C);
+            tx = xs;
+            ta = row;
+          }
+      } else {
+        for (int s = 0; s < smax; ++s)
+          if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick);  // w = spawn tick
+      }
     }
 
     // ---- phase W -------------------------------------------------------------------------------
@@ -194,7 +234,8 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
         ob[e] = (d.agent_mode && tidx > 0) ? ob[e] + kpop : kpop;
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
-      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
+                            n_tot | (HET ? last_a << 16 : 0));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
       d.leadx[id] = p.xL;
       my_updates += (unsigned long long)n_tot;

@@ -302,7 +302,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   const int4 rc = d.rec[id];    // the pass's record of the first tick
   const int4 r2 = d.rec2[id];
   const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, true, true);
-  const int m0 = rc.w - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
+  const int m0 = rec_ntot(rc.w) - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
   const int n_old = p.n_old, n_tot = p.n_tot;
 
   float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;

@@ -6,6 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libtfx_hip.so"))
 
+MAX_ARCH = 8
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
 ABI_VERSION = 10
@@ -20,7 +21,8 @@ class TfxConfig(C.Structure):
                 ("yellow_ticks", C.c_int32), ("thresh", C.c_float), ("detect_dist", C.c_float),
                 ("overflow_penalty", C.c_float), ("eps", C.c_float),
                 ("learn_switch", C.c_int32), ("validate", C.c_int32), ("entry_spec", C.c_uint32),
-                ("env_id_offset", C.c_int32), ("layout", C.c_int32)]
+                ("env_id_offset", C.c_int32), ("layout", C.c_int32),
+                ("n_archetypes", C.c_int32), ("arch", (C.c_float * 8) * 8)]
 
 
 class TfxBuffers(C.Structure):
@@ -50,6 +52,7 @@ _PROTOS = {
     "tfx_set_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_spawns": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_poisson": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int32]),
+    "tfx_set_spawn_archetypes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "tfx_move_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
     "tfx_advance_finished_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -64,8 +67,8 @@ _PROTOS = {
     "tfx_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "tfx_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "tfx_xv_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    "tfx_export_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tfx_import_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tfx_export_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tfx_import_ring": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tfx_fastdiv_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "tfx_launch_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int32)] * 3),
     "tfx_arrivals_replay": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,

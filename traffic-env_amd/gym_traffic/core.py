@@ -75,18 +75,32 @@ class PackedMirror(object):
 class TfxEngine(object):
     def __init__(self, m, n, length, capacity, n_envs=1, rate=0.5, learn_switch=False,
                  validate=False, entry_spec=0, planes=None, trip_cap=4096, device=None, env_id_offset=0,
-                 layout=None):
+                 layout=None, archetypes=None):
+        """archetypes: rows (v, l, a, delta, v0, b, T, s0) of the reference's `archetypes` table
+        (traffic_env.py:35-43) when there is more than its single default row, or a delta other than 4
+        ("heterogeneous cars": needs planes = 3 and the transposed layout; every car keeps its row, see
+        set_spawns(..., rows=) and the `arch` property)."""
         if not torch.cuda.is_available():
             raise nat.TfxError("no GPU visible: the traffic env step runs on MI355X only (no CPU fallback)")
         self.lib = nat.lib()
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.m, self.n, self.C, self.E = int(m), int(n), int(capacity), int(n_envs)
-        self.P = int(planes) if planes else (3 if validate else 2)
+        arch = None if archetypes is None else np.asarray(archetypes, np.float32).reshape(-1, 8)
+        self.het = arch is not None and (len(arch) > 1 or float(arch[0, 3]) != 4.0)
+        self.archetypes = arch
+        self.P = int(planes) if planes else (3 if (validate or self.het) else 2)
         cfg = nat.TfxConfig()
         cfg.m, cfg.n, cfg.capacity, cfg.n_envs, cfg.planes = self.m, self.n, self.C, self.E, self.P
         cfg.length, cfg.rate = float(length), float(rate)
         for k, v in ARCHETYPE.items():
             setattr(cfg, k, v)
+        if arch is not None:
+            if len(arch) > nat.MAX_ARCH:
+                raise ValueError("at most %d archetype rows" % nat.MAX_ARCH)
+            cfg.n_archetypes = len(arch)
+            for a, row in enumerate(arch):
+                for j in range(8):
+                    cfg.arch[a][j] = float(row[j])
         for k, v in CONSTANTS.items():
             setattr(cfg, k, v)
         cfg.learn_switch, cfg.validate = int(bool(learn_switch)), int(bool(validate))
@@ -129,12 +143,14 @@ class TfxEngine(object):
             # use: a rollout that never looks at the cars does not pay a second copy of them
             self._ring = None
             self._ringw = None
+            self._ringa = None
             self._tw = torch.zeros((self._t.shape[0],), dtype=torch.float32, device=dev) if P == 3 else None
         else:
             self._t = None
             self._ring = torch.zeros((E, R, Cc, 2), dtype=torch.float32, device=dev)
             # spawn ticks (validate mode): ring-shaped like the cars
             self._ringw = torch.zeros((E, R, Cc), dtype=torch.float32, device=dev) if P == 3 else None
+            self._ringa = None
             self._tw = None
         # transposed handles: `_epoch` counts calls that move the cars; the staging copy mirrors the
         # device state only while `_stage_epoch` equals it
@@ -195,19 +211,23 @@ class TfxEngine(object):
             self._ring = torch.zeros((self.E, self.R, self.C, 2), dtype=torch.float32, device=self.device)
             if self.P == 3:
                 self._ringw = torch.zeros((self.E, self.R, self.C), dtype=torch.float32, device=self.device)
+            if self.het:
+                self._ringa = torch.zeros((self.E, self.R, self.C), dtype=torch.uint8, device=self.device)
 
     def drop_staging(self):
         """Free the ring-shaped staging copy of a transposed handle (it comes back on the next access)."""
         if self._t is not None:
             self._ring = None
             self._ringw = None
+            self._ringa = None
             self._stage_epoch = -1
 
     def _export(self):
         if self._t is not None:
             self._staging()
             with torch.cuda.device(self.device):
-                nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
+                nat.check(self.lib.tfx_export_ring(self.h, _ptr(self._ring), _ptr(self._ringw), _ptr(self._ringa),
+                                                   self._stream()))
             self._stage_epoch = self._epoch
 
     @property
@@ -224,6 +244,15 @@ class TfxEngine(object):
             return None
         self._export()
         return self._ringw
+
+    @property
+    def arch(self):
+        """[E,R,C] uint8: row of the archetype table each ring slot's car was spawned from (None unless the
+        engine has heterogeneous cars); same staging rule as `xv`."""
+        if not self.het:
+            return None
+        self._export()
+        return self._ringa
 
     @property
     def x(self):
@@ -288,7 +317,8 @@ class TfxEngine(object):
                     raise nat.TfxError("refresh(): the ring-layout staging copy behind xv / x / v / w is stale (the cars "
                                        "moved since it was exported); read eng.xv again before editing it, call "
                                        "drop_staging() to discard it, or refresh(cars=False) to rebuild the tails only")
-                nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), _ptr(self._ringw), self._stream()))
+                nat.check(self.lib.tfx_import_ring(self.h, _ptr(self._ring), _ptr(self._ringw), _ptr(self._ringa),
+                                                   self._stream()))
             nat.check(self.lib.tfx_refresh(self.h, self._stream()))
 
     def set_poisson(self, cars_per_tick, seed=0):
@@ -336,9 +366,20 @@ class TfxEngine(object):
             nat.check(self.lib.tfx_set_actions(self.h, mode, _ptr(a), 0, 1 if per_tick else 0))
             self._action_bound = key
 
-    def set_spawns(self, counts=None, period=None, per_tick=False):
+    def set_spawns(self, counts=None, period=None, per_tick=False, rows=None):
         """counts: int [E,n_entry] (with per_tick: [n_ticks,E,n_entry]); period: on-device
-        one-car-every-`period`-ticks per entry road; neither: no spawns.  Buffers as in set_actions."""
+        one-car-every-`period`-ticks per entry road; neither: no spawns.  Buffers as in set_actions.
+        rows (heterogeneous cars): uint8 [E,n_entry,S] (per_tick: [n_ticks,E,n_entry,S]) - the archetype-table
+        row of the j-th car each entry road receives this tick (cars past S, or all without `rows`: row 0)."""
+        if self.het and counts is not None:
+            if rows is None:
+                nat.check(self.lib.tfx_set_spawn_archetypes(self.h, None, 0, 0))
+                self._rows_buf = None
+            else:
+                r8 = torch.as_tensor(np.ascontiguousarray(rows, np.uint8)).to(self.device) if not isinstance(rows, torch.Tensor) \
+                    else rows.to(device=self.device, dtype=torch.uint8).contiguous()
+                self._rows_buf = r8
+                nat.check(self.lib.tfx_set_spawn_archetypes(self.h, _ptr(r8), int(r8.shape[-1]), 1 if per_tick else 0))
         if period is not None:
             key = ("periodic", int(period))
             if self._spawn_bound != key:
@@ -362,6 +403,14 @@ class TfxEngine(object):
         elif self._spawn_bound != ("none",):
             nat.check(self.lib.tfx_set_spawns(self.h, nat.SPAWN_NONE, None, 0, 0))
             self._spawn_bound = ("none",)
+
+    def set_spawn_rows(self, rows, per_tick=False):
+        """Heterogeneous cars: uint8 [E,n_entry,S] (per_tick: [n_ticks,E,n_entry,S]) archetype-table row of the j-th
+        car each entry road receives (tfx_set_spawn_archetypes); pairs with the count buffer already bound."""
+        r8 = torch.as_tensor(np.ascontiguousarray(rows, np.uint8)).to(self.device) if not isinstance(rows, torch.Tensor) \
+            else rows.to(device=self.device, dtype=torch.uint8).contiguous()
+        self._rows_buf = r8
+        nat.check(self.lib.tfx_set_spawn_archetypes(self.h, _ptr(r8), int(r8.shape[-1]), 1 if per_tick else 0))
 
     def _as_dev_i32(self, a, key):
         """-> (int32 device tensor, owned).  Device tensors pass through (owned False).  Host arrays
@@ -560,10 +609,12 @@ class TfxEngine(object):
         return x, v, w
 
     # ---- bulk state import (tests, checkpoint restore) ----------------------------------------
-    def load_state(self, x, v, leading, lastcar, w=None):
-        """x, v[, w]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
+    def load_state(self, x, v, leading, lastcar, w=None, arch=None):
+        """x, v[, w][, arch]: [E,R,C]; leading/lastcar: [E,R].  Rebuilds the kernel's tail cache."""
         self._staging()
         self._stage_epoch = self._epoch
+        if self._ringa is not None and arch is not None:
+            self._ringa.copy_(torch.as_tensor(np.asarray(arch, np.uint8)).to(self.device))
         self._ring[..., 0].copy_(torch.as_tensor(np.asarray(x, np.float32)).to(self.device))
         self._ring[..., 1].copy_(torch.as_tensor(np.asarray(v, np.float32)).to(self.device))
         if self._ringw is not None and w is not None:

@@ -115,30 +115,56 @@ class DeviceView(object):
         return "DeviceView(%r)" % (self.numpy(),)
 
 
-class StateView(DeviceView):
-    """env.state as the reference shapes it: float32 [R, 3, C] with planes (x, v, w).  Reads gather
-    the planes from the device; `state[...] = value` writes them back and refreshes the engine."""
+ARCH_COLS = [vi, li, ai, deltai, v0i, bi, ti, s0i]     # engine row order: v, l, a, delta, v0, b, T, s0
 
-    def __init__(self, eng):
+
+class StateView(DeviceView):
+    """env.state as the reference shapes it (traffic_env.py:364): float32 [R, 10, C], `state[e, p, s]` = parameter
+    p (xi, vi, li, ai, deltai, v0i, bi, ti, s0i, wi) of the car in ring slot s of road e - so readers written against
+    the reference (`state[i, [xi, li], ...]` in update_locs, :348-358) work unchanged.  The device keeps x, v, w (and
+    the archetype row) per car; a read assembles the ten planes: live slots carry their car's x, v, w and the seven
+    constants of its archetype row, the fake leader's slot carries its x and zeros (as :262-263 leaves it), dead
+    slots are zero (the reference leaves np.empty garbage there).  `state[...] = value` writes x, v, w - and, with
+    several archetypes, the row whose constants the slot now holds - back to the device."""
+
+    def __init__(self, eng, table):
         self._eng = eng
+        self._table = np.asarray(table, np.float32)            # [n, 10]
 
     def numpy(self):
-        x, v, w = self._eng.planes_numpy()
-        return np.stack([x[0], v[0], w[0]], axis=1)
+        eng = self._eng
+        x, v, w = eng.planes_numpy()
+        ld, lc = eng.leading[0].cpu().numpy(), eng.lastcar[0].cpu().numpy()
+        slots = np.arange(eng.C)[None, :]
+        l2, c2 = ld[:, None], lc[:, None]
+        live = np.where(l2 <= c2, (slots > l2) & (slots <= c2), (slots > l2) | ((slots >= 1) & (slots <= c2))) & (l2 != c2)
+        rows = eng.arch[0].cpu().numpy().astype(np.int64) if eng.het else np.zeros((eng.R, eng.C), np.int64)
+        st = np.transpose(self._table[rows], (0, 2, 1)) * live[:, None, :]          # [R, 10, C]
+        st[:, xi, :] = np.where(live | (slots == l2), x[0], 0)
+        st[:, vi, :] = np.where(live, v[0], 0)
+        st[:, wi, :] = np.where(live, w[0], 0)
+        return np.ascontiguousarray(st, np.float32)
 
     def __setitem__(self, idx, value):
         a = self.numpy()
         a[idx] = value
         eng = self._eng
-        eng.load_state(a[None, :, 0, :], a[None, :, 1, :], eng.leading.cpu().numpy(),
-                       eng.lastcar.cpu().numpy(), w=a[None, :, 2, :])
+        arch = None
+        if eng.het:
+            key = [li, ai, deltai, v0i, bi, ti, s0i]
+            arch = np.zeros((eng.R, eng.C), np.uint8)
+            for row in range(self._table.shape[0]):
+                arch[(a[:, key, :] == self._table[row, key][None, :, None]).all(axis=1)] = row
+            arch = arch[None]
+        eng.load_state(a[None, :, xi, :], a[None, :, vi, :], eng.leading.cpu().numpy(),
+                       eng.lastcar.cpu().numpy(), w=a[None, :, wi, :], arch=arch)
 
     def __len__(self):
         return self._eng.R
 
     @property
     def shape(self):
-        return (self._eng.R, 3, self._eng.C)
+        return (self._eng.R, params, self._eng.C)
 
 
 class TrafficEnv(gym.Env):
@@ -178,14 +204,19 @@ class TrafficEnv(gym.Env):
     def _build_engine(self):
         from gym_traffic.core import TfxEngine
         g = self.graph
+        # the module's `archetypes` table, read when the engine is built like the reference's generators read it
+        # when a car is made (traffic_env.py:164): rows beyond the first, or another exponent, switch the engine to
+        # per-car parameters
+        table = np.array(archetypes, np.float32).reshape(-1, params)
         self.engine = TfxEngine(g.m, g.n, float(g.len), self.capacity, n_envs=1,
                                 rate=float(FLAGS.rate), learn_switch=bool(flag('learn_switch', False)),
                                 validate=self._validate, entry_spec=self._spec, planes=3,
-                                device=self.device)
-        self._built = (float(FLAGS.rate), bool(flag('learn_switch', False)), self._validate, self._spec)
+                                device=self.device, archetypes=table[:, ARCH_COLS])
+        self._built = (float(FLAGS.rate), bool(flag('learn_switch', False)), self._validate, self._spec,
+                       table[:, ARCH_COLS].tobytes())
         eng = self.engine
-        # [R, 3, C] = the reference's state[:, (xi, vi, wi), :]; a read assembles it from the device
-        self.state = StateView(eng)
+        # [R, 10, C] as the reference shapes it; a read assembles it from the device
+        self.state = StateView(eng, table)
         # ring semantics for `env.leading[i] = k`: the cars keep their SLOTS, so the slot image is
         # exported under the old indices before the write and imported under the new ones after it
         self.leading = DeviceView(lambda: eng.leading[0], eng.refresh, before_write=eng._export)
@@ -204,7 +235,8 @@ class TrafficEnv(gym.Env):
         225,237,240).  They are baked into the device config, so a change rebuilds the engine
         around the current state."""
         now = (float(FLAGS.rate), bool(flag('learn_switch', False)),
-               flag('mode', 'train') == 'validate', self._spec)
+               flag('mode', 'train') == 'validate', self._spec,
+               np.array(archetypes, np.float32).reshape(-1, params)[:, ARCH_COLS].tobytes())
         if now == self._built:
             return
         old = self.engine
@@ -272,6 +304,8 @@ class TrafficEnv(gym.Env):
         if flag('learn_switch', False):
             act = (act != 0)
         eng.stage_inputs(act.astype(np.int32), self._spawn_counts)
+        if eng.het:
+            eng.set_spawn_rows(self._rows_of([roads], [self._schedule.rows]))
         first = eng.tick
         eng.step(1, update_done=False)
         self.steps += 1
@@ -291,15 +325,19 @@ class TrafficEnv(gym.Env):
         if getattr(self, '_rep_counts', None) is None or self._rep_counts.shape[0] != n:
             self._rep_counts = np.zeros((n, 1, max(1, eng.n_entry)), np.int32)
         mark = self._mark_spawner()
-        made = []
+        made, all_roads, all_rows = [], [], []
         for t in range(n):
             roads = self._spawns()
             made.append(len(roads))
+            all_roads.append(roads)
+            all_rows.append(self._schedule.rows)
             counts_from_roads(roads, eng.entry_index, eng.n_entry, out=self._rep_counts[t, 0])
         act = np.asarray(action)
         if flag('learn_switch', False):
             act = (act != 0)
         eng.stage_inputs(act.astype(np.int32), self._rep_counts, per_tick=True)
+        if eng.het:
+            eng.set_spawn_rows(self._rows_of(all_roads, all_rows), per_tick=True)
         first = eng.tick
         eng.agent_step(n, remi=False)
         if self._mirror_rep is None:
@@ -325,6 +363,20 @@ class TrafficEnv(gym.Env):
         if self._validate:
             self._collect_trips(int(got["n_trips"][0]))
         return total_obs, total_reward, done
+
+    def _rows_of(self, roads_per_tick, rows_per_tick):
+        """uint8 [n_ticks, 1, n_entry, S]: archetype row of the j-th car each entry road receives in each tick."""
+        eng = self.engine
+        per = [{} for _ in roads_per_tick]
+        for t, (roads, rows) in enumerate(zip(roads_per_tick, rows_per_tick)):
+            for rd, a in zip(roads, rows):
+                per[t].setdefault(eng.entry_index[rd], []).append(a)
+        S = max([len(v) for d in per for v in d.values()] + [1])
+        out = np.zeros((len(per), 1, max(1, eng.n_entry), S), np.uint8)
+        for t, d in enumerate(per):
+            for j, v in d.items():
+                out[t, 0, j, :len(v)] = v
+        return out if len(per) > 1 else out[0]
 
     def _mark_spawner(self):
         s = getattr(self, '_schedule', None)

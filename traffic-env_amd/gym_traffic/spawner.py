@@ -4,7 +4,8 @@
 generators of the reference and the entry-road draw of `add_new_cars` (traffic_env.py:160-176 and
 :274-283), so that `seed_generator(seed)` yields the same (tick, road) sequence as the reference -
 "identical seeds/spawns".  RNG draws per car, in order: `exponential` (gap to the next car, Poisson
-only), `randint(n_archetypes)`, `choice(entrypoints)`.  The device only ever sees per-tick counts.
+only), `randint(n_archetypes)`, `choice(entrypoints)`.  The device sees per-tick counts (and, with several archetypes,
+the table row of every car).
 
 Two of those calls are issued in a cheaper, stream-identical form (tests/test_host_logic.py checks
 both against the literal calls): `choice(a)` of a 1-D array draws `randint(0, len(a))` and indexes,
@@ -47,8 +48,7 @@ class SpawnSchedule(object):
             if self._gap > 0:
                 self._gap -= 1
                 return n
-            if self.n_archetypes > 1:
-                self.rand.randint(self.n_archetypes)   # archetype pick
+            self.rows.append(int(self.rand.randint(self.n_archetypes)) if self.n_archetypes > 1 else 0)   # archetype pick
             self._gap = None
             n += 1
             self._roads.append(int(self.entrypoints[self.rand.randint(0, len(self.entrypoints))]))
@@ -58,13 +58,15 @@ class SpawnSchedule(object):
         self._i += 1
         if due:
             for _ in range(self._burst):
+                self.rows.append(0)           # (the regular generator yields archetypes[0], traffic_env.py:174)
                 self._roads.append(int(self.entrypoints[self.rand.randint(0, len(self.entrypoints))]))
 
     def next_tick(self):
-        """Entry roads of the cars created this tick, in creation order."""
+        """Entry roads of the cars created this tick, in creation order (`rows`: the archetype-table row of each)."""
         if not self._started:
             self._start()
         self._roads = []
+        self.rows = []
         if self.poisson:
             self._poisson_tick()
         else:

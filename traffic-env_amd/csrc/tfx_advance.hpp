@@ -148,11 +148,21 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
 // Item 0 of an env flagged for it runs the literal serial loop for the whole env.
 template <bool TL>
 __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int tick, int tidx) {
-  if (env_frozen(d, env, tick)) return;  // stopped for the rest of this agent step
-  const bool serial = d.env_flag[env] == tick + 1;
+  const bool frozen = env_frozen(d, env, tick);  // stopped for the rest of this agent step
+  const bool serial = !frozen && d.env_flag[env] == tick + 1;
+  // The greedy controller's decision for the NEXT tick, from the counts this tick leaves behind: the lane of
+  // intersection s has just settled its four incoming roads (an env on the serial path: its one lane decides for
+  // every intersection; an env that stands still keeps deciding from its standing counts, as an agent would).
+  const bool decide = d.greedy_spacing > 0 && (tick + 1) % d.greedy_spacing == 0;
+  if (frozen) {
+    if (decide && s < d.I) d.greedy_act[(size_t)env * d.I + s] = greedy_decide(d, env, s);
+    return;
+  }
   if (serial && s == 0) {
     if (TL) advance_env_serial_t(d, env, tick, tidx);
     else advance_env_serial(d, env, tick, tidx);
+    if (decide)
+      for (int i = 0; i < d.I; ++i) d.greedy_act[(size_t)env * d.I + i] = greedy_decide(d, env, i);
   }
   if (s < d.I) {
     int ph_new, el_new;
@@ -169,6 +179,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
       for (int j = 0; j < ovf; ++j) rw -= d.ovf_pen;
       d.rewards[(size_t)env * d.I + s] = rw;
       if (ovf > 0) d.done_tick[env] = tick + 1;
+      if (decide) d.greedy_act[(size_t)env * d.I + s] = greedy_decide(d, env, s);
     }
     int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
     ob[s] = ph_new;

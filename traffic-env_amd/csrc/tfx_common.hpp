@@ -72,6 +72,10 @@ struct Dev {
   const int *spawn;
   int spawn_mode, spawn_period;
   long spawn_stride;
+  // greedy controller (algorithms/greedy.py:14-16): > 0 = the advance of tick t writes the action of tick t + 1
+  // whenever (t + 1) % greedy_spacing == 0
+  int greedy_spacing;
+  int *greedy_act;               // [E][I]
   // heterogeneous cars (tfx_config.n_archetypes): every car's side word w holds 8 * spawn tick + table row
   int het;
   const float *arch_tab;         // [TFX_MAX_ARCH][ARCH_W]: l, a, v0, T, s0, 2 sqrt(a b), delta, spawn speed
@@ -320,6 +324,18 @@ __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 // rec.w: cars on the road during the move (incl. this tick's arrivals) | table row of the last of them << 16
 __device__ __forceinline__ int rec_ntot(int rw) { return rw & 0xffff; }
 __device__ __forceinline__ int rec_taila(int rw) { return rw >> 16; }
+
+// greedy.py:14-16: phase 1 iff the two N-S approaches hold more cars than the two E-W ones
+// (cars_on_roads().dot([1,1,-1,-1]) < 0) at intersection i of env
+__device__ __forceinline__ int greedy_decide(const Dev &d, int env, int i) {
+  int c[4];
+#pragma unroll
+  for (int dir = 0; dir < 4; ++dir) {
+    const int id = env * d.R + dir * d.I + i;
+    c[dir] = ring_count(d.leading[id], d.lastcar[id], d.C);
+  }
+  return (c[0] + c[1] - c[2] - c[3] < 0) ? 1 : 0;
+}
 
 // The pull-form advance is exact unless (a) a road pops more than TFX_KP cars, (b) a popped car
 // would itself be popped again downstream this tick, or (c) a full ring pops two or more cars

@@ -120,6 +120,7 @@ struct tfx_handle_s {
   // on-device Poisson arrivals / greedy controller (own buffers)
   bool poisson = false, greedy = false;
   int greedy_spacing = 3;
+  int poisson_rows = 1;        // ticks of arrival counts the Poisson buffer holds (tfx_step generates a call's worth up front)
   PoissonDev ps{};
   void *dev_ps = nullptr;      // counts | gap_left | draws | cdf
   int *dev_greedy = nullptr;   // [E][I] actions
@@ -265,10 +266,10 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   }
   const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
   if (pvar == 90 || (tiles <= split_below && pvar == 0)) {
-    auto gs = [&](auto kern) {
+    auto gs = [&](auto kern, int threads = 256) {
       if (h->grid_move == 0) h->grid_move = (int)(tiles < (long)h->n_cu * 8 ? tiles : (long)h->n_cu * 8);
       if (h->size_only) return (int)TFX_OK;
-      hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
+      hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(threads), 0, st, h->d, tidx);
       HIPCHK(hipGetLastError());
       return (int)TFX_OK;
     };
@@ -281,6 +282,9 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     }
     if (cap <= 32) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<8>); }
     if (cap <= 64) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16>); }
+    // long roads on a launch of at most ~two tiles per CU: eight segments of 16 cars instead of four of 32
+    // (cfg4 x 1 env closed loop: 38.4 -> 28.6 us per tick)
+    if (cap <= 128 && cap > 64 && tiles <= (long)h->n_cu * 2) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16, false, 8>, 512); }
     if (cap <= 128) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<32>); }
     { h->step_kernel = "k_move_ts"; return gs(k_move_ts<64>); }
   }
@@ -332,18 +336,30 @@ int grid_for(long items, int n_cu) {
   return (int)g;
 }
 
-// per-tick producers of the spawn counts / actions when they are generated on the device
+// The on-device Poisson stream for the next n_ticks ticks (rows of the count buffer); one workgroup per env, as
+// many lanes as the burst is long (cfg4: thousands of cars per tick).
+int launch_poisson(tfx_handle h, int n_ticks, hipStream_t st) {
+  const Dev &d = h->d;
+  const int threads = d.E <= 64 ? 1024 : (d.E <= 1024 ? 256 : 64);
+  const int pg = d.E < h->n_cu * 16 ? d.E : h->n_cu * 16;
+  hipLaunchKernelGGL(k_poisson, dim3(pg), dim3(threads), ((size_t)d.n_entry + 2) * sizeof(int), st, d, h->ps, n_ticks);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+// Producers of the inputs of ONE tick when they are generated on the device tick by tick: the Poisson stream inside
+// agent steps and single launches (tfx_step generates whole calls up front, see there).  The greedy controller's
+// decisions are made by the advance of the tick before (advance_item); k_greedy runs once per call.
 int launch_inputs(tfx_handle h, hipStream_t st) {
-  if (h->poisson) {
-    const int pg = h->d.E < h->n_cu * 16 ? h->d.E : h->n_cu * 16;
-    hipLaunchKernelGGL(k_poisson, dim3(pg), dim3(64), (size_t)h->d.n_entry * sizeof(int), st, h->d, h->ps);
-    HIPCHK(hipGetLastError());
-  }
-  if (h->greedy) {
-    hipLaunchKernelGGL(k_greedy, dim3(grid_for((long)h->d.E * h->d.I, h->n_cu)), dim3(256), 0, st, h->d,
-                       h->dev_greedy, h->greedy_spacing);
-    HIPCHK(hipGetLastError());
-  }
+  if (h->poisson && h->d.spawn_stride == 0) return launch_poisson(h, 1, st);
+  return TFX_OK;
+}
+
+int launch_greedy(tfx_handle h, hipStream_t st) {
+  if (!h->greedy) return TFX_OK;
+  hipLaunchKernelGGL(k_greedy, dim3(grid_for((long)h->d.E * h->d.I, h->n_cu)), dim3(256), 0, st, h->d,
+                     h->dev_greedy, h->greedy_spacing);
+  HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
@@ -552,6 +568,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   s.env_flag = d.env_flag + L;
   s.env_risk = d.env_risk + L;
   if (d.action_mode == TFX_ACTION_BUFFER && d.action) s.action = d.action + L * I;
+  if (d.greedy_act) s.greedy_act = d.greedy_act + L * I;
   if (d.spawn_mode == TFX_SPAWN_COUNTS && d.spawn) s.spawn = d.spawn + L * (size_t)d.n_entry;
   if (clock) {
     s.tickA = clock;
@@ -562,10 +579,11 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
 }
 
 // k_tail (tfx_tail.hpp) replaces k_advance(t) k_edge(t+1) k_advance(t+1) behind a two-tick pass: one workgroup per
-// env.  Not when the inputs of t+1 are produced on the device between the two ticks (Poisson arrivals, greedy
-// controller), and not below one env per CU (a handful of big envs - cfg4 - has too few workgroups to offer).
+// env.  Not when the arrivals of t+1 are produced by a launch between the two ticks (the Poisson stream tick by tick:
+// agent steps; tfx_step generates them up front), and not below one env per CU (a handful of big envs - cfg4 - has
+// too few workgroups to offer).  (The greedy controller decides inside the advance.)
 bool tail_usable(tfx_handle h) {
-  if (!h->tail || h->poisson || h->greedy || h->d.layout != 1 || h->d.w) return false;
+  if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1 || h->d.w) return false;
   return h->tail == 2 || h->d.E >= h->n_cu;
 }
 
@@ -631,6 +649,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   }
   hipLaunchKernelGGL(k_agent_begin, dim3(1), dim3(1), 0, st, d, const_cast<int *>(d.agent_first));
   HIPCHK(hipGetLastError());
+  if (int rc = launch_greedy(h, st)) return rc;
   d.agent_mode = 1;
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
@@ -728,6 +747,8 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
 }
 
 }  // namespace
+
+int step_chunk(tfx_handle h, int n_ticks, hipStream_t st);
 
 extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
                               uint8_t *adone, void *stream) {
@@ -1091,6 +1112,8 @@ int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t peri
   Dev &d = h->d;
   ++h->input_gen;
   h->greedy = false;
+  d.greedy_spacing = 0;
+  d.greedy_act = nullptr;
   if (mode == TFX_ACTION_GREEDY) {
     if (period < 1) return fail(TFX_EINVAL, "greedy spacing must be >= 1");
     if (!h->dev_greedy) {
@@ -1099,6 +1122,8 @@ int tfx_set_actions(tfx_handle h, int32_t mode, const int32_t *dev, int32_t peri
     }
     h->greedy = true;
     h->greedy_spacing = period;
+    d.greedy_spacing = period;
+    d.greedy_act = h->dev_greedy;
     d.action = h->dev_greedy;
     d.action_stride = 0;
     d.action_mode = TFX_ACTION_BUFFER;
@@ -1162,7 +1187,10 @@ int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uin
                                       "tfx_set_spawns + tfx_set_spawn_archetypes");
   ++h->input_gen;
   if (h->dev_ps) { (void)hipFree(h->dev_ps); h->dev_ps = nullptr; }
-  const size_t n_counts = (size_t)d.E * d.n_entry;
+  // rows of E x n_entry counts: tfx_step generates that many ticks per launch (at most 64, at most ~32 MB)
+  long rows = ((long)32 << 20) / ((long)d.E * d.n_entry * 4);
+  h->poisson_rows = (int)(rows < 1 ? 1 : (rows > 64 ? 64 : rows));
+  const size_t n_counts = (size_t)h->poisson_rows * d.E * d.n_entry;
   const size_t bytes = (n_counts + 2 * (size_t)d.E + (size_t)n_cdf) * 4;
   HIPCHK(hipMalloc(&h->dev_ps, bytes));
   HIPCHK(hipMemset(h->dev_ps, 0, bytes));
@@ -1203,6 +1231,28 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     }
     return TFX_OK;
   }
+  if (int rc = launch_greedy(h, st)) return rc;  // (the decision of the call's first tick; later ones: advance_item)
+  if (h->poisson && n_ticks > 0) {
+    // the arrivals of the whole call (in chunks of the rows the count buffer holds) in ONE launch each: they depend
+    // on nothing but the stream, and a launch per tick was the longest one of a cfg4 tick
+    int rc = TFX_OK;
+    for (int done = 0; done < n_ticks && rc == TFX_OK;) {
+      const int chunk = n_ticks - done < h->poisson_rows ? n_ticks - done : h->poisson_rows;
+      rc = launch_poisson(h, chunk, st);
+      h->d.spawn_stride = (long)h->d.E * h->d.n_entry;
+      if (rc == TFX_OK) rc = step_chunk(h, chunk, st);
+      h->d.spawn_stride = 0;
+      done += chunk;
+    }
+    return rc;
+  }
+  return step_chunk(h, n_ticks, st);
+}
+
+}  // extern "C"
+
+// n_ticks ticks on the per-tick kernels, the env range in two halves on two streams where that pays
+int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
     if (!h->split_stream) {
@@ -1241,8 +1291,11 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   return step_range(h, n_ticks, st);
 }
 
+extern "C" {
+
 int tfx_move_cars(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
+  if (int rc = launch_greedy(h, (hipStream_t)stream)) return rc;
   if (int rc = launch_inputs(h, (hipStream_t)stream)) return rc;
   return pairs_usable(h) ? launch_move_tt<false>(h, 0, (hipStream_t)stream) : launch_move(h, 0, (hipStream_t)stream);
 }

@@ -175,56 +175,71 @@ struct PoissonDev {
 };
 
 // Draw indexing (fixed, so the stream is random-access): draw 0 = the first gap; car c (0-based)
-// uses draw 1 + 2c for its entry road and draw 2 + 2c for the gap that follows it.  One wavefront
-// per env evaluates 64 consecutive cars at a time: all cars up to and including the first one with
-// a non-zero gap arrive in this tick (the reference's generator yields bursts at high rates:
-// thousands of cars per tick at cfg4's nominal 15 cars/tick because gaps are rounded to ticks).
-__global__ __launch_bounds__(64) void k_poisson(const Dev d, const PoissonDev ps) {
-  extern __shared__ int s_hist[];  // [n_entry]
-  const int lane = threadIdx.x;
+// uses draw 1 + 2c for its entry road and draw 2 + 2c for the gap that follows it.  One WORKGROUP per env
+// evaluates blockDim.x consecutive cars at a time: all cars up to and including the first one with a non-zero
+// gap arrive in this tick (the reference's generator yields bursts at high rates: thousands of cars per tick
+// at cfg4's nominal 15 cars/tick because gaps are rounded to ticks - with one wavefront per env that was 28 us
+// per tick, the longest launch of a cfg4 tick; 1024 lanes take the burst in two or three rounds).
+// n_ticks > 1: the counts of that many consecutive ticks, rows of E x n_entry each (tfx_step generates a whole
+// call's arrivals up front: they depend on nothing but the stream).  Inside an agent step (n_ticks = 1) an env
+// that stands still consumes nothing.
+__global__ __launch_bounds__(1024) void k_poisson(const Dev d, const PoissonDev ps, const int n_ticks) {
+  extern __shared__ int s_hist[];  // [n_entry] + 2 words
+  int *s_first = s_hist + d.n_entry;  // lowest car index (relative) whose gap is non-zero | its gap
+  const int tid = threadIdx.x, nthr = blockDim.x;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
-    for (int j = lane; j < d.n_entry; j += 64) s_hist[j] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (!env_frozen(d, env, *d.tickA)) {
-      int gap = ps.gap_left[env];
-      unsigned c0 = ps.draws[env];  // index of the next car
-      const unsigned gid = (unsigned)(env + d.env_off);
-      unsigned u[4];
-      auto gap_of = [&](unsigned draw) {
-        philox4x32(draw, gid, 0x47415021u, 0u, ps.seed_lo, ps.seed_hi, u);
-        int k = 0;
-        while (k < ps.n_cdf - 1 && u[0] >= ps.cdf[k]) ++k;  // cdf[n_cdf-1] catches the tail
-        return k;
-      };
-      if (gap < 0) gap = gap_of(0u);
-      if (gap > 0) {
-        --gap;
-      } else {
-        for (int guard = 0; guard < 1024; ++guard) {  // <= 65536 cars per env-tick
-          const unsigned c = c0 + (unsigned)lane;
-          const int g = gap_of(2u + 2u * c);
-          const unsigned long long stop = __builtin_amdgcn_ballot_w64(g > 0);
-          const int f = stop ? __builtin_ctzll(stop) : 63;  // last car of this tick within the batch
-          if (lane <= f) {
-            philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
-            atomicAdd(&s_hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
-          }
-          c0 += (unsigned)(f + 1);
-          if (stop) {
-            gap = __shfl(g, f, 64) - 1;
-            break;
+    const bool frozen = n_ticks == 1 && env_frozen(d, env, *d.tickA);
+    int gap = ps.gap_left[env];
+    unsigned c0 = ps.draws[env];  // index of the next car
+    const unsigned gid = (unsigned)(env + d.env_off);
+    unsigned u[4];
+    auto gap_of = [&](unsigned draw) {
+      philox4x32(draw, gid, 0x47415021u, 0u, ps.seed_lo, ps.seed_hi, u);
+      int k = 0;
+      while (k < ps.n_cdf - 1 && u[0] >= ps.cdf[k]) ++k;  // cdf[n_cdf-1] catches the tail
+      return k;
+    };
+    __syncthreads();  // (every lane has read the env's state before lane 0 of an earlier iteration's store is overtaken)
+    for (int t = 0; t < n_ticks; ++t) {
+      for (int j = tid; j < d.n_entry; j += nthr) s_hist[j] = 0;
+      __syncthreads();
+      if (!frozen) {
+        if (gap < 0) gap = gap_of(0u);
+        if (gap > 0) {
+          --gap;
+        } else {
+          for (int guard = 0; guard < 4096; ++guard) {  // (a burst ends with probability 1 - cdf[0] per car)
+            if (tid == 0) { s_first[0] = 0x7fffffff; }
+            __syncthreads();
+            const unsigned c = c0 + (unsigned)tid;
+            const int g = gap_of(2u + 2u * c);
+            if (g > 0) atomicMin(&s_first[0], tid);
+            __syncthreads();
+            const int first = s_first[0];
+            const int f = first < nthr ? first : nthr - 1;  // last car of this tick within the batch
+            if (tid <= f) {
+              philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
+              atomicAdd(&s_hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
+            }
+            if (tid == f) s_first[1] = g;
+            c0 += (unsigned)(f + 1);
+            __syncthreads();
+            if (first < nthr) {
+              gap = s_first[1] - 1;
+              break;
+            }
           }
         }
       }
-      if (lane == 0) {
-        ps.gap_left[env] = gap;
-        ps.draws[env] = c0;
-      }
+      __syncthreads();
+      int *row = ps.counts + ((size_t)t * d.E + env) * d.n_entry;
+      for (int j = tid; j < d.n_entry; j += nthr) row[j] = s_hist[j];
+      __syncthreads();
     }
-    __builtin_amdgcn_wave_barrier();
-    int *row = ps.counts + (size_t)env * d.n_entry;
-    for (int j = lane; j < d.n_entry; j += 64) row[j] = s_hist[j];
-    __builtin_amdgcn_wave_barrier();
+    if (tid == 0 && !frozen) {
+      ps.gap_left[env] = gap;
+      ps.draws[env] = c0;
+    }
   }
 }
 
@@ -232,20 +247,15 @@ __global__ __launch_bounds__(64) void k_poisson(const Dev d, const PoissonDev ps
 // N-S approaches hold more cars than the two E-W ones (cars_on_roads().dot([1,1,-1,-1]) < 0);
 // between decisions the action is held.  One lane per intersection; runs before k_move so the
 // counts are the ones an agent would observe before stepping.
+// Launched once at the start of a call (the cars may have been edited from outside since the last tick); inside a
+// call the advance of tick t leaves the decision for tick t + 1 behind (greedy_decide in advance_item).
 __global__ void k_greedy(const Dev d, int *action, int spacing) {
   const int tick = *d.tickA;
   if (tick % spacing != 0) return;
   const long total = (long)d.E * d.I;
   for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
     const int env = (int)(g / d.I);
-    const int i = (int)(g - (long)env * d.I);
-    int c[4];
-#pragma unroll
-    for (int dir = 0; dir < 4; ++dir) {
-      const int id = env * d.R + dir * d.I + i;
-      c[dir] = ring_count(d.leading[id], d.lastcar[id], d.C);
-    }
-    action[g] = (c[0] + c[1] - c[2] - c[3] < 0) ? 1 : 0;
+    action[g] = greedy_decide(d, env, (int)(g - (long)env * d.I));
   }
 }
 

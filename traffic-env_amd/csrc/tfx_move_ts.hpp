@@ -20,9 +20,9 @@
 
 namespace tfx {
 
-template <int KS, bool W = false>  // KS cars per segment held in registers: C - 2 <= 4 * KS; W: spawn-tick plane
-__global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
-  constexpr int S = 4;
+// KS cars per segment held in registers: C - 2 <= S * KS; W: spawn-tick plane; S segments (wavefronts) per tile
+template <int KS, bool W = false, int S = 4>
+__global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx) {
   __shared__ int s_wait[S][64], s_det[S][64], s_kpop[64];
   __shared__ float s_tail[64];
   const int lane = threadIdx.x & 63;
@@ -179,8 +179,12 @@ __global__ __launch_bounds__(256) void k_move_ts(const Dev d, const int tidx) {
     __syncthreads();
 
     if (seg == 0 && run) {
-      const int tot_wait = s_wait[0][lane] + s_wait[1][lane] + s_wait[2][lane] + s_wait[3][lane];
-      const int tot_det = s_det[0][lane] + s_det[1][lane] + s_det[2][lane] + s_det[3][lane];
+      int tot_wait = 0, tot_det = 0;
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        tot_wait += s_wait[q][lane];
+        tot_det += s_det[q][lane];
+      }
       const int kpop_all = s_kpop[lane];
       if (p.n_tot != p.n_old) d.lastcar[id] = p.lc;
       if (e < d.r) {

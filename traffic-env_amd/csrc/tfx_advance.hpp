@@ -146,20 +146,20 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
 // One work item of the advance: s < I is intersection s of the env (its four incoming roads s, I+s, 2I+s, 3I+s,
 // roadgraph.py:38-39, plus the light words and the reward of that intersection), s >= I is exit road r + (s - I).
 // Item 0 of an env flagged for it runs the literal serial loop for the whole env.
-template <bool TL>
+template <bool TL, bool HET = false, bool GREEDY = false>
 __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int tick, int tidx) {
   const bool frozen = env_frozen(d, env, tick);  // stopped for the rest of this agent step
   const bool serial = !frozen && d.env_flag[env] == tick + 1;
   // The greedy controller's decision for the NEXT tick, from the counts this tick leaves behind: the lane of
   // intersection s has just settled its four incoming roads (an env on the serial path: its one lane decides for
   // every intersection; an env that stands still keeps deciding from its standing counts, as an agent would).
-  const bool decide = d.greedy_spacing > 0 && (tick + 1) % d.greedy_spacing == 0;
+  const bool decide = GREEDY && d.greedy_spacing > 0 && (tick + 1) % d.greedy_spacing == 0;
   if (frozen) {
     if (decide && s < d.I) d.greedy_act[(size_t)env * d.I + s] = greedy_decide(d, env, s);
     return;
   }
   if (serial && s == 0) {
-    if (TL) advance_env_serial_t(d, env, tick, tidx);
+    if (TL) advance_env_serial_t<HET>(d, env, tick, tidx);
     else advance_env_serial(d, env, tick, tidx);
     if (decide)
       for (int i = 0; i < d.I; ++i) d.greedy_act[(size_t)env * d.I + i] = greedy_decide(d, env, i);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
 #pragma unroll
       for (int dir = 0; dir < 4; ++dir) {
         const int e = dir * d.I + s;
-        ovf += (TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
+        ovf += (TL ? advance_road_t<HET>(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
       }
       // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
       float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
@@ -186,7 +186,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
     ob[d.I + s] = el_new;
   } else if (!serial) {
     const int e = d.r + (s - d.I);
-    const int ovf = TL ? advance_road_t(d, env, e) : advance_road(d, env, e, tick, tidx);
+    const int ovf = TL ? advance_road_t<HET>(d, env, e) : advance_road(d, env, e, tick, tidx);
     if (ovf > 0) d.done_tick[env] = tick + 1;
     if (d.validate && d.n_trips && s == d.I) {
       // advance_hack :153-154: trip times of cars leaving the map, in road order
@@ -209,7 +209,8 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
   }
 }
 
-template <bool TL>
+// GREEDY: the on-device greedy controller is on (the kernels without it keep its loads out of their registers)
+template <bool TL, bool HET = false, bool GREEDY = false>
 __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
   const int tick = *d.tickB;
   const int per_env = d.I + (d.R - d.r);
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
     if (gid == 0) *d.tickA = tick + 1;
-    advance_item<TL>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
+    advance_item<TL, HET, GREEDY>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
   }
 }
 

@@ -20,6 +20,7 @@ __device__ __forceinline__ void compact_head_rows(const Dev &d, int id, int hb, 
   d.rec[id].y &= ~(3 << 28);
 }
 
+template <bool HET = false>
 __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int C = d.C;
   const int id = env * d.R + e;
@@ -50,7 +51,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
         const float2 car = d.outb[pcol + (size_t)j * 64];
         const float xc = car.x - d.length;  // state[e,xi,newlead] -= length (:130)
         const int pos = wrap1(lc + 1, C);
-        const float tl = d.het ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = d.het ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
+        const float tl = HET ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = HET ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
         const float start = (lc != ld_seen) ? (tail_x - tl) - ts0 : INFINITY;
         if (pos != ld_seen) {
           const float xv = (start < xc) ? start : xc;
@@ -58,7 +59,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
           if (d.w) {
             const float cw = d.outw[pcol + (size_t)j * 64];
             d.w[ecol + (size_t)m * 64] = cw;
-            ta = side_arch(cw);
+            if (HET) ta = side_arch(cw);
           }
           ++m;
           lc = pos;
@@ -72,7 +73,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   }
   if (k_e > 0) d.leading[id] = ld_post;
   d.tailx[id] = tail_x;
-  if (d.het) d.taila[id] = ta;
+  if (HET) d.taila[id] = ta;
   return ovf;
 }
 
@@ -85,6 +86,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
 //                                 2 .. kpop-1, survivors behind them at their old rows, pushes behind
 //                                 those; once its pops are processed the column is shifted down by
 //                                 kpop, i.e. compacted.
+template <bool HET = false>
 __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) {
   const int C = d.C;
   int *ob = d.obs + (size_t)env * d.obs_len;
@@ -109,7 +111,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
   // move kernel processed (after a two-tick pass the rows themselves are already a tick ahead), then every push
   for (int e = 0; e < d.R; ++e) {
     d.tailx[env * d.R + e] = __int_as_float(d.rec[env * d.R + e].z);
-    if (d.het) d.taila[env * d.R + e] = rec_taila(d.rec[env * d.R + e].w);
+    if (HET) d.taila[env * d.R + e] = rec_taila(d.rec[env * d.R + e].w);
   }
   // row k of a road's column, counted from its first live row
   auto rowb = [&](int idq, int k) { return tpos(d, idq, k + rec_hb(d.rec[idq].y)); };
@@ -135,8 +137,8 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int phys = ring_count(ldn, lcn, C) - pending;          // survivors + cars pushed so far
     const int base = (pending > 0 && rec_unc(rn.y)) ? pending : 0;  // rows the pending cars occupy
     const int pos = wrap1(lcn + 1, C);
-    const int ta = d.het ? d.taila[idn] : 0;
-    const float tl = d.het ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = d.het ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
+    const int ta = HET ? d.taila[idn] : 0;
+    const float tl = HET ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = HET ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
     const float start = (lcn != ldn) ? (d.tailx[idn] - tl) - ts0 : INFINITY;
     if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
     if (pos != ldn) {
@@ -145,7 +147,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
       if (d.w) d.w[rowb(idn, base + phys)] = cw;
       d.lastcar[idn] = pos;
       d.tailx[idn] = xv;
-      if (d.het) d.taila[idn] = side_arch(cw);
+      if (HET) d.taila[idn] = side_arch(cw);
     } else {
       if (nr < d.r) rew[nr % d.I] -= d.ovf_pen;
       overflowed = 1;

@@ -493,8 +493,17 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
     h->grid_adv = (int)(g < 1 ? 1 : g);
   }
   if (h->size_only) return TFX_OK;
-  if (d.layout == 1) hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
-  else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+  const bool g = h->greedy;
+  if (h->het) {
+    if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL((k_advance<true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+  } else if (d.layout == 1) {
+    if (g) hipLaunchKernelGGL((k_advance<true, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+  } else {
+    if (g) hipLaunchKernelGGL((k_advance<false, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+  }
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -530,11 +539,29 @@ int edge_grid(tfx_handle h) {
 // AGENT: inside an agent step; only_risky: the second tick of the envs k_risk sorted out of a pair
 template <bool TWO, bool AGENT = false>
 int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
-  int &grid = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
-  if (grid == 0) grid = move_grid(h, k_move_tt<TWO, AGENT>, 256, 0, 6);
+  // Grid: 10 workgroups per CU, 6 of them resident at once.  Measured at cfg2 (ms per pass alone on the chip
+  // / vehicle-updates per second of the split call, same box): 6 workgroups per CU - every one resident for the whole
+  // launch - 0.741 / 5.22-5.26e11; 10-12 per CU 0.706-0.719 / 5.26e11; 24 per CU 0.682 / 5.15e11; one tile per
+  // wavefront (68 per CU) 0.681 / 5.12e11; another box 6 / 10 / 12 per CU: 0.749 / 0.716 / 0.722 and 5.13 / 5.14 /
+  // 5.08e11.  A second, partial round of workgroups evens out the end of the launch; more rounds
+  // cost the split call more than they give the launch.  (Grids of a whole number of workgroups per CU: an "exactly
+  // balanced" 2902 instead of 3072 workgroups took 0.756.)
+  int &resident = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
+  if (resident == 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 6) per_cu = 6;
+    resident = h->n_cu * per_cu;
+  }
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
-  hipLaunchKernelGGL((k_move_tt<TWO, AGENT>), dim3(grid), dim3(256), 0, st, h->d, tidx, only_risky);
+  long grid = (long)resident / 6 * 10;
+  if (const char *pc = getenv("TFX_MOVE_BLOCKS_PER_CU")) grid = atoi(pc) > 0 ? (long)atoi(pc) * h->n_cu : grid;
+  const long need = ((long)h->d.E * h->d.G + 3) / 4;
+  if (grid > need) grid = need;
+  if (grid >= 8) grid -= grid % 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_move_tt<TWO, AGENT>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -603,13 +630,15 @@ bool split_usable(tfx_handle h, int n_ticks) {
 int launch_tail(tfx_handle h, int tidx, hipStream_t st) {
   if (h->grid_tail == 0) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 5 && h->greedy) per_cu = 5;
     long g = (long)h->n_cu * per_cu;
     if (g > h->d.E) g = h->d.E;
     h->grid_tail = (int)(g < 1 ? 1 : g);
   }
   if (h->size_only) return TFX_OK;
-  hipLaunchKernelGGL(k_tail, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+  if (h->greedy) hipLaunchKernelGGL(k_tail<true>, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+  else hipLaunchKernelGGL(k_tail<false>, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -1256,7 +1285,11 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
     if (!h->split_stream) {
-      HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+      int lo_p = 0, hi_p = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+      const char *pv = getenv("TFX_SPLIT_PRIO");
+      const int prio = pv ? (atoi(pv) > 0 ? hi_p : (atoi(pv) < 0 ? lo_p : 0)) : 0;
+      HIPCHK(hipStreamCreateWithPriority(&h->split_stream, hipStreamNonBlocking, prio));
       HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
     }

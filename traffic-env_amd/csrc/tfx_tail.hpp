@@ -23,6 +23,7 @@
 
 namespace tfx {
 
+template <bool GREEDY = false>
 __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -33,12 +34,12 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true>(d, env, s, tick, tidx);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY>(d, env, s, tick, tidx);
     __syncthreads();
     for (int g = wv; g < d.G; g += nwv)
       my_updates += (unsigned long long)edge_tile<false>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1);
     __syncthreads();
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true>(d, env, s, tick + 1, tidx + 1);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY>(d, env, s, tick + 1, tidx + 1);
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);

@@ -296,7 +296,7 @@ def test_pmc_summary_tells_the_move_kernels_apart():
     assert ps.short("void tfx::k_move_tt<true, false>(tfx::Dev, int, int)") == "k_move_tt"
     assert ps.short("void tfx::k_move_tt<false, false>(tfx::Dev, int, int)") == "k_move_tt1"
     assert ps.short("void tfx::k_move_t<4, 3, false>(tfx::Dev, int)") == "k_move_t"
-    assert ps.short("void tfx::k_move_t2<4, 3>(tfx::Dev, int)") == "k_move_t2"
+    assert ps.short("void tfx::k_tail<false>(tfx::Dev, int)") == "k_tail"
     assert ps.short("void tfx::k_move_ts<16, false>(tfx::Dev, int)") == "k_move_ts"
     assert ps.short("void tfx::k_edge<false>(tfx::Dev, int)") == "k_edge"
     assert ps.short("void tfx::k_advance<true>(tfx::Dev, int)") == "k_advance"

@@ -22,7 +22,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t2", "k_move_t", "k_move")
+MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t", "k_move")
 
 
 def csrc_hash():
@@ -39,7 +39,7 @@ def csrc_hash():
 def short(name):
     if "k_move_tt<false" in name:
         return "k_move_tt1"          # the one-tick form that ends a call of two-tick passes
-    for k in MOVERS + ("k_edge", "k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
+    for k in MOVERS + ("k_tail", "k_edge", "k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
                        "k_poisson", "k_greedy", "k_agent_obs"):
         if k + "<" in name or k + "(" in name or name.strip().endswith(k):
             return k
@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--kernel", default=None, help="the kernel whose traffic goes into pmc_<config>.json")
     ap.add_argument("--ticks-per-launch", type=int, default=1,
                     help="ticks one launch of that kernel covers (k_res: the n of tfx_step(n); k_move_tt: 2)")
+    ap.add_argument("--read-bytes-expected", type=float, default=0.0,
+                    help="bytes the kernel is known to read per launch (for the record of the FETCH_SIZE factor)")
     ap.add_argument("--hash", action="store_true", help="print the current csrc hash and exit")
     a = ap.parse_args()
     if a.hash:
@@ -104,7 +106,20 @@ def main():
                   "k_move_hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
                   "hbm_bytes_per_tick": (fetch * 1024 * 2 + write * 1024) / a.ticks_per_launch,
                   "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests of wide streaming reads as 64 B); "
-                                "WRITE_SIZE as reported", "note": a.note}
+                                "WRITE_SIZE as reported",
+                  # why x2 holds for THIS kernel's 8-byte-per-lane row loads and not only for the guide's 16-byte
+                  # ones: the launch reads every live car once (16 N_live... 8 B each) and the raw counter comes out
+                  # at half of that
+                  "correction_basis": "the kernel's read side is known exactly - 8 B per live car + the per-road words "
+                                      "- and FETCH_SIZE x 1024 comes out at %.3f of it; tools/copy_probe.hip's "
+                                      "in-place stream of a known byte count shows the same factor "
+                                      "(profiles/r01_copy_bandwidth_probe.txt)" % (a.read_bytes_expected and
+                                      fetch * 1024 / a.read_bytes_expected or float("nan")),
+                  "note": a.note}
+            if (mv, "SQ_INSTS_VALU") in agg:
+                v = sum(agg[(mv, "SQ_INSTS_VALU")]) / len(agg[(mv, "SQ_INSTS_VALU")])
+                js["valu_insts_per_launch"] = v
+                js["valu_insts_per_tick"] = v / a.ticks_per_launch
             json.dump(js, open(os.path.join(out, "pmc_%s.json" % a.config), "w"), indent=1)
             print(json.dumps(js))
 

@@ -18,6 +18,9 @@ prof() {  # name, rocprof args..., -- bench args
 }
 # BENCH_ONLY=1: only the un-profiled bench lines below
 [ "${BENCH_ONLY:-0}" = 1 ] || {
+# Per-kernel numbers are taken with the env range in ONE piece (TFX_SPLIT=0): a launch that shares the chip with the
+# other half's launches has no duration of its own.  cfg2_split_kt is the default (split) run for the record.
+export TFX_SPLIT=0
 for cfg in cfg2 cfg1 cfg4; do
   prof ${cfg}_kt --kernel-trace --stats -- --config $cfg
   prof ${cfg}_fetch --kernel-trace --pmc FETCH_SIZE -- --config $cfg
@@ -28,7 +31,8 @@ done
 TFX_PAIRS=0 prof cfg2_pertick_kt --kernel-trace --stats -- --config cfg2
 TFX_PAIRS=0 prof cfg2_pertick_fetch --kernel-trace --pmc FETCH_SIZE -- --config cfg2
 TFX_PAIRS=0 prof cfg2_pertick_write --kernel-trace --pmc WRITE_SIZE -- --config cfg2
-TFX_RESIDENT=0 prof cfg1_pertick_kt --kernel-trace --stats -- --config cfg1
+unset TFX_SPLIT
+prof cfg2_split_kt --kernel-trace --stats -- --config cfg2
 }
 cd $R
 # (cfg0 / cfg1: k_res runs the whole timed region as ONE launch of 2 ms per 200 ticks: timed over 2000)
@@ -40,9 +44,12 @@ done
 TFX_PAIRS=0 python3 bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_pertick.json 2>/dev/null
 TFX_PAIRS=0 python3 bench.py --config cfg4 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg4_pertick.json 2>/dev/null
 TFX_RESIDENT=0 python3 bench.py --config cfg1 --steps 200 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_pertick.json 2>/dev/null
+TFX_SPLIT=0 python3 bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_nosplit.json 2>/dev/null
+TFX_SPLIT=0 TFX_TAIL=0 python3 bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_nosplit_notail.json 2>/dev/null
 python3 bench.py --config cfg1 --envs 4096 --steps 1000 --warmup 600 --no-cpu-baseline > $O/bench_cfg1_4096.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 256 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_256.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg2_32768.json 2>/dev/null
 ( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt
+( python3 tools/run_cfg4.py; python3 tools/c4_quick.py ) 2>&1 | grep -v amdgpu.ids > $O/cfg4_closed_loop.txt
 ( python3 tools/bench_agent_step.py cfg2; TFX_PAIRS=0 python3 tools/bench_agent_step.py cfg2 ) 2>&1 | grep -v amdgpu.ids > $O/agent_step_cfg2.txt
 echo finished

@@ -97,8 +97,10 @@ def main():
         have = [k for k in MOVERS if (k, "FETCH_SIZE") in agg and (k, "WRITE_SIZE") in agg]
         mv = a.kernel or (max(have, key=lambda k: total_ns.get(k, 0)) if have else None)
         if mv and (mv, "FETCH_SIZE") in agg and (mv, "WRITE_SIZE") in agg:
-            fetch = sum(agg[(mv, "FETCH_SIZE")]) / len(agg[(mv, "FETCH_SIZE")])
-            write = sum(agg[(mv, "WRITE_SIZE")]) / len(agg[(mv, "WRITE_SIZE")])
+            def med(v):    # (the median: a profile run's first launches differ - cold caches, k_res's shorter warm-up call)
+                v = sorted(v)
+                return 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
+            fetch, write = med(agg[(mv, "FETCH_SIZE")]), med(agg[(mv, "WRITE_SIZE")])
             js = {"kernel": mv, "config": a.config, "round": a.round, "csrc_hash": csrc_hash(),
                   "ticks_per_launch": a.ticks_per_launch,
                   "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
@@ -111,13 +113,13 @@ def main():
                   # ones: the launch reads every live car once (16 N_live... 8 B each) and the raw counter comes out
                   # at half of that
                   "correction_basis": "the kernel's read side is known exactly - 8 B per live car + the per-road words "
-                                      "- and FETCH_SIZE x 1024 comes out at %.3f of it; tools/copy_probe.hip's "
-                                      "in-place stream of a known byte count shows the same factor "
-                                      "(profiles/r01_copy_bandwidth_probe.txt)" % (a.read_bytes_expected and
+                                      "- and FETCH_SIZE x 1024 comes out at %.3f of it; a stream of KNOWN size (tools/fetch_factor.sh "
+                                      "over tools/copy_probe.hip, 8 and 16 bytes per lane) reads 0.500 x its bytes on "
+                                      "FETCH_SIZE and 1.000 x on WRITE_SIZE (profiles/r03_fetch_size_factor.txt)" % (a.read_bytes_expected and
                                       fetch * 1024 / a.read_bytes_expected or float("nan")),
                   "note": a.note}
             if (mv, "SQ_INSTS_VALU") in agg:
-                v = sum(agg[(mv, "SQ_INSTS_VALU")]) / len(agg[(mv, "SQ_INSTS_VALU")])
+                v = med(agg[(mv, "SQ_INSTS_VALU")])
                 js["valu_insts_per_launch"] = v
                 js["valu_insts_per_tick"] = v / a.ticks_per_launch
             json.dump(js, open(os.path.join(out, "pmc_%s.json" % a.config), "w"), indent=1)

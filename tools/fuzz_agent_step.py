@@ -23,6 +23,8 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 4])))
     os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))
     os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))     # two-tick passes + k_risk forced at any size | never
+    os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2])))         # (plain step() calls between decisions: k_tail, split)
+    os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))
     eng = TfxEngine(m, nn, L, C, n_envs=E, planes=2 if layout == "transposed" else 3, layout=layout)
     orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
     ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)

@@ -29,7 +29,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS")}
+    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS", "TFX_TAIL", "TFX_SPLIT")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -60,14 +60,30 @@ def _run(rng, seed, LIMIT):
         os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))
         os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2])))    # lanes per road of k_res
         os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))    # two-tick passes (k_move_tt + k_edge) forced at any size | never
+        os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2, 2])))     # ... finished by k_tail | by three launches
+        os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))       # ... the env range in two halves on two streams
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
-        eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout)
+        # heterogeneous cars (one case in five on the transposed layout): a random table of 1..4 rows, exponents 1..8
+        het = layout == "transposed" and rng.randint(5) == 0
+        tab8 = tab10 = None
+        if het:
+            na = int(rng.randint(1, 5))
+            tab8 = np.stack([np.array([rng.uniform(5, 14), rng.choice([3.0, 4.0, 7.5, 12.0]), rng.uniform(0.8, 4), float(rng.randint(1, 9)),
+                                       rng.uniform(8, 18), rng.uniform(2, 8), rng.uniform(1, 3), rng.uniform(0.5, 3)], np.float32) for _ in range(na)])
+            if na == 1 and tab8[0, 3] == 4.0: tab8[0, 3] = 2.0      # (one row with delta = 4 is the single-archetype path)
+            tab10 = np.zeros((na, 10), np.float32); tab10[:, [1, 2, 3, 4, 5, 6, 7, 8]] = tab8
+            planes = 3
+        eng = TfxEngine(m, nn, L, C, n_envs=E, rate=rate, learn_switch=ls, validate=val, entry_spec=spec, planes=planes, layout=layout, archetypes=tab8)
         orc = OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, rate=rate, learn_switch=ls, validate=val)
         if rng.randint(2):
             x, v, w, ld, lc = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.2, 0.6, 0.9]), beyond=rng.choice([0.0, 0.1, 0.5, 1.7]), sorted_x=bool(rng.randint(2)))
             ph = rng.randint(2, size=(E, eng.I)).astype(np.int32); el = rng.randint(0, 12, size=(E, eng.I)).astype(np.int32)
             load_both(eng, orc, x, v, w, ld, lc, ph, el)
+            if het:
+                arch = rng.randint(0, len(tab8), size=x.shape).astype(np.uint8)
+                eng.load_state(x, v, ld, lc, w=w, arch=arch)
+                for kk in range(E): orc.load_planes(kk, x[kk], v[kk], w[kk], ld[kk], lc[kk], arch=arch[kk], archetypes=tab10)
             eng.set_tick(60); orc.steps[:] = 60; orc.n_trips[:] = 0
             if val: eng.n_trips.zero_()
         else:
@@ -77,10 +93,21 @@ def _run(rng, seed, LIMIT):
             k = int(min(T - t, rng.choice([1, 1, 2, 3, 4, 5, 10])))
             acts = rng.randint(2, size=(k, E, eng.I)).astype(np.int32)
             roads = [[(rng.choice(eng.entrypoints, size=rng.poisson(dens)).tolist() if eng.n_entry else []) for _ in range(E)] for _ in range(k)]
-            eng.set_actions(acts, per_tick=True); eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True)
+            rows = None
+            if het:      # the table row of every arriving car, parallel to `roads`; the device gets them per (tick, env, entry road, j)
+                rows = [[rng.randint(0, len(tab8), size=len(r)).tolist() for r in rt] for rt in roads]
+                S = max([1] + [np.bincount(r, minlength=1).max() if len(r) else 1 for rt in roads for r in rt])
+                buf = np.zeros((k, E, max(1, eng.n_entry), S), np.uint8)
+                for j in range(k):
+                    for kk in range(E):
+                        seen = {}
+                        for rd, a in zip(roads[j][kk], rows[j][kk]):
+                            q = seen.get(rd, 0); seen[rd] = q + 1
+                            buf[j, kk, eng.entry_index[rd], q] = a
+            eng.set_actions(acts, per_tick=True); eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True, rows=buf if het else None)
             eng.step(k)
             done = np.zeros(E, bool)
-            for j in range(k): done |= orc.step(acts[j], roads[j])[2].astype(bool)
+            for j in range(k): done |= orc.step(acts[j], roads[j], spawn_arch=rows[j] if het else None, archetypes=tab10)[2].astype(bool)
             assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), (n, t)
             t += k
             if rng.randint(4) == 0:        # the cold entry points too
@@ -113,7 +140,13 @@ def _run(rng, seed, LIMIT):
                                 if a.view(np.int32) != b.view(np.int32) and not (np.isnan(a) and np.isnan(b)):
                                     print("DIFF tick", t, "k", k, "env", kk, "road", e, "car", i, "of", cnt, nm, "gpu", a, "oracle", b,
                                           "pred", int(np.where(eng.nexts == e)[0][0]) if (eng.nexts == e).any() else -1, "next", int(eng.nexts[e]), flush=True)
-            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ["TFX_PAIRS"], t))
+            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s tail=%s split=%s het=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ["TFX_PAIRS"], os.environ["TFX_TAIL"], os.environ["TFX_SPLIT"], het, t))
+            if het:
+                a_dev = eng.arch.cpu().numpy(); ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+                from oracle.oracle import live_mask
+                for kk in range(E):
+                    lv = live_mask(ldh[kk], lch[kk], C)
+                    assert np.array_equal(a_dev[kk][lv], orc.arch_plane(kk, tab10)[lv]), ("arch rows", n, t, kk)
         if val:
             nt = eng.n_trips.cpu().numpy(); assert np.array_equal(nt, orc.n_trips), n
             for kk in range(E): assert np.array_equal(eng.trip_times[kk, :min(nt[kk], eng.trip_cap)].cpu().numpy(), orc.trip_times[kk, :min(nt[kk], eng.trip_cap)]), n

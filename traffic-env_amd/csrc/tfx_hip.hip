@@ -74,7 +74,12 @@ struct tfx_handle_s {
   // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)
   int split = 1;              // TFX_SPLIT=0 never, 2 at any batch size
   hipStream_t split_stream = nullptr;
-  hipEvent_t split_fork = nullptr, split_join = nullptr;
+  hipEvent_t split_fork = nullptr, split_join = nullptr, split_stagger = nullptr;
+  // which half of a split call is being enqueued (-1: none) and whether its first pass is still to come: the second
+  // half's first pass waits for the first half's (from then on a half's pass runs under the other half's k_tail; left to
+  // themselves both halves start their passes together and only fall into step a pair or two later)
+  int split_half = -1;
+  bool split_first = false;
   int *tick2 = nullptr;       // clock words of the second half (tickA, tickB), risk word
   bool het = false;           // heterogeneous cars (tfx_config.n_archetypes)
   float *dev_arch = nullptr;  // the archetype table on the device
@@ -477,7 +482,7 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   return TFX_OK;
 }
 
-int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
+int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   const Dev &d = h->d;
   if (h->grid_adv == 0) {
     // no more blocks than are resident at once (k_advance<true> holds 5 per CU): with 8 per CU launched the
@@ -495,14 +500,14 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   if (h->size_only) return TFX_OK;
   const bool g = h->greedy;
   if (h->het) {
-    if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
-    else hipLaunchKernelGGL((k_advance<true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    else hipLaunchKernelGGL((k_advance<true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
   } else if (d.layout == 1) {
-    if (g) hipLaunchKernelGGL((k_advance<true, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
-    else hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    if (g) hipLaunchKernelGGL((k_advance<true, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    else hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
   } else {
-    if (g) hipLaunchKernelGGL((k_advance<false, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
-    else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    if (g) hipLaunchKernelGGL((k_advance<false, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
   }
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -561,8 +566,12 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   if (grid > need) grid = need;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
+  const bool stagger = TWO && h->split_first && h->split_half >= 0;
+  if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
   hipLaunchKernelGGL((k_move_tt<TWO, AGENT>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
   HIPCHK(hipGetLastError());
+  if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));
+  if (stagger) h->split_first = false;
   return TFX_OK;
 }
 
@@ -627,18 +636,23 @@ bool split_usable(tfx_handle h, int n_ticks) {
 
 // (256 lanes per workgroup and as many workgroups as fit, measured at cfg2 against 512 / 1024 lanes and 2 / 3
 // workgroups per CU: 0.088 ms per tick against 0.090-0.131 - the launch lives on wavefronts in flight)
-int launch_tail(tfx_handle h, int tidx, hipStream_t st) {
+int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false) {
   if (h->grid_tail == 0) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<false>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_tail<false, false>), 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 5 && h->greedy) per_cu = 5;
     long g = (long)h->n_cu * per_cu;
     if (g > h->d.E) g = h->d.E;
     h->grid_tail = (int)(g < 1 ? 1 : g);
   }
   if (h->size_only) return TFX_OK;
-  if (h->greedy) hipLaunchKernelGGL(k_tail<true>, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
-  else hipLaunchKernelGGL(k_tail<false>, dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+  if (agent) {
+    if (h->greedy) hipLaunchKernelGGL((k_tail<true, true>), dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+    else hipLaunchKernelGGL((k_tail<false, true>), dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+  } else {
+    if (h->greedy) hipLaunchKernelGGL((k_tail<true, false>), dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+    else hipLaunchKernelGGL((k_tail<false, false>), dim3(h->grid_tail), dim3(256), 0, st, h->d, tidx);
+  }
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
@@ -660,9 +674,21 @@ int launch_risk(tfx_handle h, int tidx, hipStream_t st) {
 
 namespace {
 
+// the second stream of a split call and the events that fork it from / join it to the caller's stream
+int ensure_split(tfx_handle h) {
+  if (h->split_stream) return TFX_OK;
+  HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->split_stagger, hipEventDisableTiming));
+  return TFX_OK;
+}
+
 // the launches of one agent step, in order, on `st`
+// split: the ticks run as two halves of the env range, the second on the handle's own stream (as step_chunk does for
+// tfx_step; launched eagerly - a batch big enough to split is not bound by its launches)
 int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
-                   hipStream_t st, long long &n_fused, long long &n_pair) {
+                   hipStream_t st, long long &n_fused, long long &n_pair, bool split = false) {
   Dev &d = h->d;
   n_fused = n_pair = 0;
   const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
@@ -682,7 +708,29 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.agent_mode = 1;
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
-  {
+  const Dev whole = h->d;
+  if (split) {
+    h->size_only = true;  // (grids are sized for the whole range)
+    (void)launch_move_tt<true, true>(h, 0, nullptr);
+    (void)launch_move_tt<false, true>(h, 0, nullptr);
+    (void)launch_tail(h, 0, nullptr, true);
+    (void)launch_advance(h, 0, nullptr);
+    h->size_only = false;
+    (void)edge_grid(h);
+    HIPCHK(hipEventRecord(h->split_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
+    HIPCHK(hipGetLastError());
+  }
+  hipStream_t user_st = st;
+  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
+    if (split) {
+      const int n0 = whole.E / 2;
+      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
+      st = half == 0 ? user_st : h->split_stream;
+      h->split_half = half;
+      h->split_first = true;
+    }
     int t = 0;
     const bool tt = pairs_usable(h);
     if (tt) {
@@ -692,11 +740,18 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         rc = launch_inputs(h, st);
         if (rc == TFX_OK) rc = launch_risk(h, t, st);
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
-        if (rc == TFX_OK) rc = launch_advance(h, t, st);
-        if (rc == TFX_OK) rc = launch_inputs(h, st);
-        if (rc == TFX_OK) rc = launch_edge<true>(h, t + 1, st);
-        if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 1);
-        if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
+        if (rc == TFX_OK && tail_usable(h)) {
+          // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
+          rc = launch_tail(h, t, st, true);
+          if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 2);
+          if (rc == TFX_OK) rc = launch_advance(h, t + 1, st, 1);
+        } else {
+          if (rc == TFX_OK) rc = launch_advance(h, t, st);
+          if (rc == TFX_OK) rc = launch_inputs(h, st);
+          if (rc == TFX_OK) rc = launch_edge<true>(h, t + 1, st);
+          if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 1);
+          if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
+        }
         if (rc == TFX_OK) n_pair += 2;
       }
     }
@@ -704,6 +759,16 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
       rc = launch_inputs(h, st);
       if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
       if (rc == TFX_OK) rc = launch_advance(h, t, st);
+    }
+    if (split) h->d = whole;
+  }
+  h->split_half = -1;
+  st = user_st;
+  if (split) {
+    n_pair /= 2;  // (both halves counted them)
+    if (rc == TFX_OK) {
+      HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+      HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
     }
   }
   d.agent_mode = keep_mode;
@@ -788,12 +853,18 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
                             "with per_tick = 0)");
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
-  if (!h->use_graph) {
+  // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
+  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
+  if (split) {
+    if (int rc = ensure_split(h)) return rc;
+  }
+  if (!h->use_graph || split) {
     long long nf = 0, np = 0;
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np);
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np, split);
     if (rc == TFX_OK) {
       h->fused_ticks += nf;
       h->pair_ticks += np;
+      if (split) h->split_ticks += n_ticks;
     }
     return rc;
   }
@@ -821,6 +892,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       h->size_only = true;
       (void)launch_move_tt<true, true>(h, 0, nullptr);
       (void)launch_move_tt<false, true>(h, 0, nullptr);
+      (void)launch_tail(h, 0, nullptr, true);
       h->size_only = false;
       (void)edge_grid(h);
     }
@@ -1057,6 +1129,7 @@ int tfx_destroy(tfx_handle h) {
     (void)hipStreamDestroy(h->split_stream);
     (void)hipEventDestroy(h->split_fork);
     (void)hipEventDestroy(h->split_join);
+    (void)hipEventDestroy(h->split_stagger);
   }
   if (h->dev_ps) (void)hipFree(h->dev_ps);
   if (h->dev_greedy) (void)hipFree(h->dev_greedy);
@@ -1284,15 +1357,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
 int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
-    if (!h->split_stream) {
-      int lo_p = 0, hi_p = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
-      const char *pv = getenv("TFX_SPLIT_PRIO");
-      const int prio = pv ? (atoi(pv) > 0 ? hi_p : (atoi(pv) < 0 ? lo_p : 0)) : 0;
-      HIPCHK(hipStreamCreateWithPriority(&h->split_stream, hipStreamNonBlocking, prio));
-      HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
-    }
+    if (int rc = ensure_split(h)) return rc;
     if (h->grid_tt[1] == 0 || h->grid_tt[0] == 0 || h->grid_tail == 0) {  // grids are sized for the whole range
       h->size_only = true;
       (void)launch_move_tt<true>(h, 0, nullptr);
@@ -1310,9 +1375,12 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
     int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
     for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
       h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
+      h->split_half = half;
+      h->split_first = true;
       rc = step_range(h, n_ticks, half == 0 ? st : h->split_stream);
       h->d = whole;
     }
+    h->split_half = -1;
     if (rc != TFX_OK) return rc;
     h->pair_ticks = pair0 + (h->pair_ticks - pair0) / 2;  // (both halves counted them)
     h->tail_ticks = tail0 + (h->tail_ticks - tail0) / 2;

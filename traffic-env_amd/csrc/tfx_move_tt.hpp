@@ -47,7 +47,8 @@ namespace tfx {
 
 // AGENT: inside an agent step - frozen envs are skipped, `passed` accumulates over the step, tiles of risky
 // envs (env_risk == tick + 1) take the one-tick form; only_risky: nothing but the tiles of envs marked risky
-// for the pair that began one tick earlier (the second tick of those envs)
+// for the pair that began one tick earlier (the second tick of those envs); only_risky = 2: the same behind k_tail,
+// which has already moved the clock past the pair (the tick is tickA - 1)
 #ifndef TT_P
 #define TT_P 4
 #endif
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
   constexpr int P = TT_P;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tick = *d.tickA;
+  const int tick = *d.tickA - ((AGENT && only_risky == 2) ? 1 : 0);
   const int C = d.C;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
 
-  if (AGENT && only_risky && *d.risk_any != tick) return;  // (k_edge has moved every env and the clock)
+  if (AGENT && only_risky && *d.risk_any != tick) return;  // (k_edge / k_tail has moved every other env and the clock)
 
   unsigned long long my_updates = 0;
 

@@ -54,8 +54,11 @@ scen("g2x2_entry_one", seed=1, entry='one', lcps=0.3)
 scen("g2x2_const0_jam", seed=4, actions='const0', lcps=0.3, C=12, T=200)
 scen("g3x3_default", m=3, n=3, seed=0, T=400)
 scen("g3x2_rect", m=3, n=2, seed=5, T=240, C=16, lcps=0.2)
-scen("g4x4_cfg1", m=4, n=4, L=200.0, C=34, seed=0, T=300, lcps=0.3, state_every=10)
+# the two benchmark shapes: car states of ticks 10 j and 10 j + 1 (4x4) / 30 j and 30 j + 1 (16x16), so the reference's
+# floats are compared there too (teacher-forced), not only its integers
+scen("g4x4_cfg1", m=4, n=4, L=200.0, C=34, seed=0, T=300, lcps=0.3, state_every=10, state_next=True)
 scen("g16x16_cfg2_ints", m=16, n=16, L=400.0, C=66, seed=0, T=150, lcps=0.25, state_every=0)
+scen("g16x16_cfg2", m=16, n=16, L=400.0, C=66, seed=1, T=181, lcps=0.12, state_every=30, state_next=True)
 # CAPACITY = 130 (BASELINE config 5's 128-car roads, traffic_env.py:46-47,202-212 with rings longer than one
 # wavefront): one car per entry road every two ticks - more than a signalised road discharges - so all 32 entry roads
 # grow past 64 cars (from tick ~130), reach 128, overflow (from tick 206) and wrap their rings (14 000 wrapped

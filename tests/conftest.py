@@ -93,3 +93,17 @@ def ulp_diff(a, b):
     ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
     bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
     return np.abs(ai - bi)
+
+
+def assert_floats_match_reference(x, v, gx, gv, a_max=3.0, rate=0.5, where=""):
+    """The float tolerance of ONE teacher-forced tick against the reference, stated once.  The
+    reference's NumPy float32 `**` is a platform SIMD routine within 1 ulp of the correctly rounded power the contract
+    uses, and that is the only difference.  One ulp of q**delta (<= 2^-23 for values below 2) shifts
+    dv = a (1 - q**delta - u^2) by at most a 2^-23 and can flip the rounding of the two subtractions and of v + dv rate
+    by one ulp each at the scale of the result.  So: x within 1 ulp (its increment carries half of the speed's error
+    times rate, far below an ulp of a position); v within 2 ulp, or within a_max rate 2^-22 absolute (3.6e-7 m/s for
+    the default archetype) for slow cars, whose own ulp is smaller than the shift."""
+    assert ulp_diff(x, gx).max() <= 1, where
+    dv = np.abs(np.asarray(v, np.float64) - np.asarray(gv, np.float64))
+    ok = (ulp_diff(v, gv) <= 2) | (dv <= a_max * rate * 2.0 ** -22)
+    assert ok.all(), (where, float(dv.max()), int(ulp_diff(v, gv).max()))

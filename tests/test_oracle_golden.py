@@ -3,9 +3,10 @@ reference's own TrafficEnv (oracle/gen_golden.py; /root/reference/gym_traffic/en
 
 Two tiers:
   * teacher-forced: load the reference's state at tick t, step once with the same action and
-    spawns, compare with the reference's tick t+1.  Every integer output must be EXACT and
-    x, v within TF_ULP = 1 ulp (the reference's NumPy float32 `**` is a platform SIMD routine
-    within 1 ulp of the correctly rounded power the oracle's contract uses).
+    spawns, compare with the reference's tick t+1.  Every integer output must be EXACT, x within
+    1 ulp, v within 2 ulp or a rate 2^-22 absolute (conftest.assert_floats_match_reference: the
+    reference's NumPy float32 `**` is a platform SIMD routine within 1 ulp of the correctly rounded
+    power the oracle's contract uses; one ulp of the power term can flip three later roundings).
   * free-running from reset: integers exact for the first FREE_TICKS ticks.  The model is
     chaotic near standstill (a 1-ulp difference grows ~4x per tick once a car brakes hard behind
     its leader), so bit-equal integers cannot hold for an unbounded horizon; every fixture stays
@@ -14,7 +15,7 @@ Two tiers:
 import numpy as np
 import pytest
 
-from conftest import golden_names, ulp_diff
+from conftest import assert_floats_match_reference, golden_names, ulp_diff
 from oracle.oracle import OracleEnv, live_mask
 
 TF_ULP = 1
@@ -93,8 +94,9 @@ def test_teacher_forced_every_tick(name, golden_cache):
         x, v, w = env.planes(0)
         live = live_mask(env.leading[0], env.lastcar[0], sc["C"])
         if live.any():
-            assert ulp_diff(x[live], g["state_x"][at[k]][live]).max() <= TF_ULP
-            assert ulp_diff(v[live], g["state_v"][at[k]][live]).max() <= TF_ULP
+            a_max = 3.0 if g.archetypes is None else float(g.archetypes[:, 3].max())
+            assert_floats_match_reference(x[live], v[live], g["state_x"][at[k]][live], g["state_v"][at[k]][live],
+                                          a_max=a_max, rate=sc["rate"], where=(name, k))
             assert np.array_equal(w[live], g["state_w"][at[k]][live])
             if g.archetypes is not None:   # every car still carries the row it was spawned from, through every handoff
                 assert np.array_equal(env.arch_plane(0, g.archetypes)[live], g["state_a"][at[k]][live])

@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-numpy-baseline", action="store_true")
+    ap.add_argument("--call-ticks", type=int, default=0,
+                    help="ticks per tfx_step call in the timed region (default: all K in one call; with the N > 1 "
+                         "gather: %d, one agent step)" % GATHER_EVERY)
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only check of the N > 1 plumbing (parent launch, rendezvous, gather, relay); "
                          "runs no kernel and measures nothing")
@@ -326,10 +329,12 @@ def main():
     if world > 1 and not a.no_gather:
         gather = RolloutGather(E, eng.obs_len, eng.I, device)
 
+    chunk = GATHER_EVERY if gather is not None else (a.call_ticks if a.call_ticks > 0 else 1 << 30)
+
     def run(n):
         done = 0
         while done < n:
-            k = min(GATHER_EVERY, n - done) if gather is not None else n - done
+            k = min(chunk, n - done)
             eng.step(k)
             done += k
             if gather is not None and done % GATHER_EVERY == 0:
@@ -403,6 +408,7 @@ def main():
             "mean_live_cars_per_road": updates / K / (E * eng.R),
             "ticks_in_two_tick_passes": pair_ticks,
             "ticks_split_over_two_streams": split_ticks,
+            "ticks_per_call": min(chunk, K),
             "roofline": roofline(a, c, eng, E, prof, prof_updates, gather is not None, dt_max, updates),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -179,11 +179,13 @@ def roofline(a, c, eng, E, prof, prof_updates, gathering, dt, updates):
                                "note": "SURVEY 8d's 16 B per vehicle-UPDATE x the updates of the launch: counts the "
                                        "cars once per tick although a T-tick pass moves them once; not a fraction "
                                        "of the HBM peak"},
-            # the whole timed region against the same peak: SURVEY 8d's bytes of every tick / wall time
-            "timed_region": {"algorithmic_GBs": wl.algorithmic_bytes_per_tick(
-                                 updates / max(1, a.steps), road_ticks, E * eng.I) * a.steps / dt / 1e9,
-                             "note": "per-tick model bytes of all ticks / wall time of the timed region (launches of "
-                                     "two env halves overlap there)"},
+            # the whole timed region against the same peak, same byte model: per T ticks every live car once (16 B) and
+            # the per-road / per-intersection words once per tick, over the wall time of T ticks (the launches of the two
+            # env halves overlap there, and the per-road launches are in it)
+            "timed_region": {"GBs": (16.0 * (updates / max(1, a.steps)) + tpl * (48.0 * road_ticks + 32.0 * E * eng.I))
+                                    / (tpl * dt / max(1, a.steps)) / 1e9,
+                             "frac": (16.0 * (updates / max(1, a.steps)) + tpl * (48.0 * road_ticks + 32.0 * E * eng.I))
+                                     / (tpl * dt / max(1, a.steps)) / 1e9 / HBM_PEAK_GBS},
             "measured": "HIP events on the launch stream around every launch of the kernel, in a second pass over "
                         "the same K ticks right after the timed region (no events inside the timed region; the env "
                         "range is not split over two streams while a launch is timed)"}

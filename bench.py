@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-numpy-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=None,
+                    help="untimed ticks run right after the prefill, as part of the workload's setup and before the W "
+                         "warm-up steps (default: the workload's, gym_traffic/workload.py SETTLE_TICKS; 0 = none)")
     ap.add_argument("--call-ticks", type=int, default=0,
                     help="ticks per tfx_step call in the timed region (default: all K in one call; with the N > 1 "
                          "gather: %d, one agent step)" % GATHER_EVERY)
@@ -327,6 +330,16 @@ def main():
     c = wl.CONFIGS[a.config]
     E = int(a.envs if a.envs is not None else c["envs"])
     eng = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
+    # The prefill puts the SAME platoon on every road of every env, and all of them brake at once: for the first ~25
+    # ticks every car of the batch is accelerating or braking, and the chip runs those ticks at a lower clock (same
+    # instructions, same bytes, same wave-cycles per launch - DESIGN.md 5).  The workload therefore includes settle
+    # ticks: the timed region measures traffic that has found its queues, whatever warm-up the caller asks for.
+    settle = wl.SETTLE_TICKS.get(a.config, 0) if a.settle is None else a.settle
+    for _ in range(settle // 50):
+        eng.step(50)
+    if settle % 50:
+        eng.step(settle % 50)
+    torch.cuda.synchronize(device)
     gather = None
     if world > 1 and not a.no_gather:
         gather = RolloutGather(E, eng.obs_len, eng.I, device)
@@ -398,7 +411,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe(a.config), "envs_per_gpu": E,
+            "config": {"workload": wl.describe(a.config) + ", %d untimed settle ticks after the prefill" % settle,
+                       "envs_per_gpu": E,
                        "grid": "%dx%d" % (c["m"], c["n"]), "cars_per_road_max": c["capacity"] - 2,
                        "car_layout": eng.layout,
                        "parallelism": "env-sharded x%d%s" % (

@@ -21,6 +21,9 @@ CONFIGS = {
 }
 SPAWN_PERIOD = 8
 LIGHT_PERIOD = 20
+# bench.py runs this many untimed ticks right after the prefill, before its warm-up: the prefill's identical platoons
+# all brake in the same ticks, and that start-up transient (~25 ticks) is not the traffic the benchmark is about
+SETTLE_TICKS = {"cfg2": 100, "cfg4": 100}
 
 
 def describe(name):

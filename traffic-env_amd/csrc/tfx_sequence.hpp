@@ -1,0 +1,213 @@
+// tfx_sequence.hpp - the launch sequences of tfx_step and tfx_agent_step: pairs of ticks, the env range in two halves on
+// two streams, the agent step (host side; included by tfx_hip.hip).
+#pragma once
+#include "tfx_launch.hpp"
+
+namespace {
+
+// the second stream of a split call and the events that fork it from / join it to the caller's stream
+int ensure_split(tfx_handle h) {
+  if (h->split_stream) return TFX_OK;
+  HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->split_stagger, hipEventDisableTiming));
+  return TFX_OK;
+}
+
+// the launches of one agent step, in order, on `st`
+// split: the ticks run as two halves of the env range, the second on the handle's own stream (as step_chunk does for
+// tfx_step; launched eagerly - a batch big enough to split is not bound by its launches)
+int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
+                   hipStream_t st, long long &n_fused, long long &n_pair, bool split = false) {
+  Dev &d = h->d;
+  n_fused = n_pair = 0;
+  const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
+  if (res_usable(h, n_ticks)) {
+    // every tick of the decision AND its tail (remi, observation, rewards, done flags) in one launch
+    d.agent_mode = 1;
+    d.accum_rewards = remi ? 0 : 1;
+    const int rc = launch_res(h, n_ticks, st, 1, remi, aobs, areward, adone);
+    d.agent_mode = keep_mode;
+    d.accum_rewards = keep_acc;
+    if (rc == TFX_OK) n_fused = n_ticks;
+    return rc;
+  }
+  hipLaunchKernelGGL(k_agent_begin, dim3(1), dim3(1), 0, st, d, const_cast<int *>(d.agent_first));
+  HIPCHK(hipGetLastError());
+  if (int rc = launch_greedy(h, st)) return rc;
+  d.agent_mode = 1;
+  d.accum_rewards = remi ? 0 : 1;
+  int rc = TFX_OK;
+  const Dev whole = h->d;
+  if (split) {
+    h->size_only = true;  // (grids are sized for the whole range)
+    (void)launch_move_tt<true, true>(h, 0, nullptr);
+    (void)launch_move_tt<false, true>(h, 0, nullptr);
+    (void)launch_tail(h, 0, nullptr, true);
+    (void)launch_advance(h, 0, nullptr);
+    h->size_only = false;
+    (void)edge_grid(h);
+    HIPCHK(hipEventRecord(h->split_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
+    HIPCHK(hipGetLastError());
+  }
+  hipStream_t user_st = st;
+  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
+    if (split) {
+      const int n0 = whole.E / 2;
+      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
+      st = half == 0 ? user_st : h->split_stream;
+      h->split_half = half;
+      h->split_first = true;
+    }
+    int t = 0;
+    const bool tt = pairs_usable(h);
+    if (tt) {
+      // two-tick passes (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
+      // tick at a time (k_risk)
+      for (; t + 1 < n_ticks && rc == TFX_OK; t += 2) {
+        rc = launch_inputs(h, st);
+        if (rc == TFX_OK) rc = launch_risk(h, t, st);
+        if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
+        if (rc == TFX_OK && tail_usable(h)) {
+          // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
+          rc = launch_tail(h, t, st, true);
+          if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 2);
+          if (rc == TFX_OK) rc = launch_advance(h, t + 1, st, 1);
+        } else {
+          if (rc == TFX_OK) rc = launch_advance(h, t, st);
+          if (rc == TFX_OK) rc = launch_inputs(h, st);
+          if (rc == TFX_OK) rc = launch_edge<true>(h, t + 1, st);
+          if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 1);
+          if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
+        }
+        if (rc == TFX_OK) n_pair += 2;
+      }
+    }
+    for (; t < n_ticks && rc == TFX_OK; ++t) {
+      rc = launch_inputs(h, st);
+      if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
+      if (rc == TFX_OK) rc = launch_advance(h, t, st);
+    }
+    if (split) h->d = whole;
+  }
+  h->split_half = -1;
+  st = user_st;
+  if (split) {
+    n_pair /= 2;  // (both halves counted them)
+    if (rc == TFX_OK) {
+      HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+      HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
+    }
+  }
+  d.agent_mode = keep_mode;
+  d.accum_rewards = keep_acc;
+  if (rc != TFX_OK) return rc;
+  if (remi) {
+    hipLaunchKernelGGL(k_remi, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d);
+    HIPCHK(hipGetLastError());
+  }
+  if (aobs) {
+    hipLaunchKernelGGL(k_agent_obs, dim3(grid_for((long)d.E * (2 * d.r + d.I), h->n_cu)), dim3(256), 0, st, d, aobs);
+    HIPCHK(hipGetLastError());
+  }
+  if (areward)
+    HIPCHK(hipMemcpyAsync(areward, d.rewards, (size_t)d.E * d.I * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (adone) {
+    hipLaunchKernelGGL(k_done_since, dim3(grid_for(d.E, h->n_cu)), dim3(256), 0, st, d, adone, d.agent_first);
+    HIPCHK(hipGetLastError());
+  }
+  return TFX_OK;
+}
+
+}  // namespace
+
+namespace {
+// the per-tick kernels for n_ticks ticks of the envs h->d describes (the whole handle, or one half of it), on st
+int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
+  int t = 0;
+  const bool tt = pairs_usable(h);
+  if (tt) {
+    for (; t + 1 < n_ticks; t += 2) {
+      const bool timed = h->prof && h->ev_used < h->ev_ticks;
+      hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+      if (int rc = launch_inputs(h, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[0], st));
+      if (int rc = launch_move_tt<true>(h, t, st)) return rc;
+      if (timed) HIPCHK(hipEventRecord(e[1], st));
+      if (tail_usable(h)) {
+        if (int rc = launch_tail(h, t, st)) return rc;
+        h->tail_ticks += 2;
+      } else {
+        if (int rc = launch_advance(h, t, st)) return rc;
+        if (int rc = launch_inputs(h, st)) return rc;
+        if (int rc = launch_edge<false>(h, t + 1, st)) return rc;
+        if (int rc = launch_advance(h, t + 1, st)) return rc;
+      }
+      if (timed) {
+        HIPCHK(hipEventRecord(e[2], st));
+        h->ev_weight[h->ev_used] = 2;
+        ++h->ev_used;
+      }
+      h->pair_ticks += 2;
+    }
+  }
+  for (; t < n_ticks; ++t) {
+    const bool timed = h->prof && h->ev_used < h->ev_ticks;
+    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (int rc = launch_inputs(h, st)) return rc;
+    if (timed) HIPCHK(hipEventRecord(e[0], st));
+    if (int rc = tt ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
+    if (timed) HIPCHK(hipEventRecord(e[1], st));
+    if (int rc = launch_advance(h, t, st)) return rc;
+    if (timed) {
+      HIPCHK(hipEventRecord(e[2], st));
+      h->ev_weight[h->ev_used] = 1;
+      ++h->ev_used;
+    }
+  }
+  return TFX_OK;
+}
+
+}  // namespace
+
+// n_ticks ticks on the per-tick kernels, the env range in two halves on two streams where that pays
+int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
+  if (split_usable(h, n_ticks)) {
+    // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
+    if (int rc = ensure_split(h)) return rc;
+    if (h->grid_tt[1] == 0 || h->grid_tt[0] == 0 || h->grid_tail == 0) {  // grids are sized for the whole range
+      h->size_only = true;
+      (void)launch_move_tt<true>(h, 0, nullptr);
+      (void)launch_move_tt<false>(h, 0, nullptr);
+      (void)launch_tail(h, 0, nullptr);
+      (void)launch_advance(h, 0, nullptr);
+      h->size_only = false;
+    }
+    const Dev whole = h->d;
+    const int n0 = whole.E / 2;
+    const long long pair0 = h->pair_ticks, tail0 = h->tail_ticks;
+    HIPCHK(hipEventRecord(h->split_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
+    int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
+    for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
+      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
+      h->split_half = half;
+      h->split_first = true;
+      rc = step_range(h, n_ticks, half == 0 ? st : h->split_stream);
+      h->d = whole;
+    }
+    h->split_half = -1;
+    if (rc != TFX_OK) return rc;
+    h->pair_ticks = pair0 + (h->pair_ticks - pair0) / 2;  // (both halves counted them)
+    h->tail_ticks = tail0 + (h->tail_ticks - tail0) / 2;
+    h->split_ticks += n_ticks;
+    HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+    HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
+    return TFX_OK;
+  }
+  return step_range(h, n_ticks, st);
+}

@@ -149,3 +149,37 @@ def test_vec_env_device_arrivals():
         ref.agent_step(10)
     assert torch.equal(venv.engine.leading[3:5], ref.leading) and torch.equal(venv.engine.lastcar[3:5], ref.lastcar)
     assert int(venv.cars_on_roads().sum()) > 30
+
+
+def test_poisson_generated_up_front_in_chunks(step_path):
+    """tfx_step draws the arrivals of a whole call in one launch per chunk of the rows its count buffer holds (64 ticks,
+    fewer for huge batches): one call of 150 ticks - three chunks, the second and third starting mid-call - leaves exactly
+    the state of fifteen calls of 10 ticks, and both follow the host mirror of the stream (oracle every 50 ticks)."""
+    if step_path == "resident":
+        pytest.skip("the per-tick kernels' arrival stream (k_res draws inside its launch)")
+    E, m, n, L, cap, cpt, spacing, seed = 5, 3, 3, 140.0, 20, 0.9, 3, 77
+    a = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    b = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    orc = OracleEnv(m, n, L, cap, a.dest, a.phases, a.nexts, n_envs=E)
+    ph = np.zeros((E, a.I), np.int32)
+    for e in (a, b):
+        e.reset(ph)
+        e.set_poisson(cpt, seed=seed)
+        e.set_greedy(spacing)
+    orc.reset(ph)
+    mirror = PoissonMirror(cpt, seed, a.n_entry, range(E))
+    a.step(150)
+    for _ in range(15):
+        b.step(10)
+    for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    act = np.zeros((E, a.I), np.int32)
+    for t in range(150):
+        if t % spacing == 0:
+            c = orc.cars_on_roads()
+            act = (c.reshape(E, a.I, 4).dot([1, 1, -1, -1]) < 0).astype(np.int32)
+        cnt = mirror.next_tick()
+        orc.step(act, [[int(a.entrypoints[j]) for j in range(a.n_entry) for _ in range(cnt[q, j])] for q in range(E)])
+    assert np.array_equal(a.leading.cpu().numpy(), orc.leading) and np.array_equal(a.lastcar.cpu().numpy(), orc.lastcar)
+    assert np.array_equal(a.obs.cpu().numpy(), orc.obs)
+    assert int(a.cars_on_roads_flat().sum()) > 50

@@ -46,14 +46,16 @@ def paired(T):
     return 2 * (T // 2)
 
 
-@pytest.mark.parametrize("m,n,C,length", [(2, 2, 10, 60.0), (3, 2, 20, 120.0), (4, 4, 34, 200.0),
-                                          (2, 3, 66, 400.0), (5, 3, 12, 80.0), (1, 1, 6, 50.0),
-                                          (2, 2, 130, 800.0)])
+@pytest.mark.parametrize("m,n,C,length,validate", [(2, 2, 10, 60.0, False), (3, 2, 20, 120.0, True), (4, 4, 34, 200.0, False),
+                                                   (2, 3, 66, 400.0, False), (5, 3, 12, 80.0, True), (1, 1, 6, 50.0, True),
+                                                   (2, 2, 130, 800.0, False), (3, 3, 34, 150.0, True)])
 @pytest.mark.parametrize("sorted_x", [True, False])
-def test_pairs_random_states_vs_oracle(m, n, C, length, sorted_x):
+def test_pairs_random_states_vs_oracle(m, n, C, length, validate, sorted_x):
+    """validate: the cars' spawn ticks travel through the pairs (the W forms of the pass, k_edge and k_tail) and the trip
+    times of cars leaving the map (advance_hack, traffic_env.py:139-157) come out the same"""
     rng = np.random.RandomState(8642 + C + int(sorted_x))
     E = 5
-    eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    eng = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5, validate=validate, planes=3 if validate else 2)
     orc = oracle_like(eng)
     ran = 0
     for trial, T in enumerate([3, 4, 7, 2, 5, 11, 1, 6]):
@@ -83,6 +85,12 @@ def test_pairs_random_states_vs_oracle(m, n, C, length, sorted_x):
             done |= orc.step(acts[t], roads[t])[2].astype(bool)
         assert np.array_equal(eng.done.cpu().numpy().astype(bool), done), trial
         assert_same_state(eng, orc, "trial %d (%d ticks)" % (trial, T))
+        if validate:
+            nt = eng.n_trips.cpu().numpy()
+            assert np.array_equal(nt, orc.n_trips), trial
+            for k in range(E):
+                kk = min(int(nt[k]), eng.trip_cap)
+                assert np.array_equal(eng.trip_times[k, :kk].cpu().numpy(), orc.trip_times[k, :kk]), (trial, k)
     assert eng.pair_ticks() == ran and eng.step_kernel() == "k_move_tt"
     assert eng.tail_ticks() == (ran if _TAIL[0] == "2" else 0)
     assert (eng.split_ticks() > 0) == (_TAIL[1] == "2")
@@ -208,17 +216,19 @@ def test_pairs_full_rings_pop_and_receive_in_the_second_tick(C):
     assert eng.pair_ticks() > 0 and left_in_second > 0
 
 
-@pytest.mark.parametrize("m,n,C,length", [(2, 2, 10, 60.0), (4, 4, 20, 250.0), (3, 2, 34, 200.0), (2, 2, 130, 800.0)])
+@pytest.mark.parametrize("m,n,C,length,validate", [(2, 2, 10, 60.0, False), (4, 4, 20, 250.0, True), (3, 2, 34, 200.0, False),
+                                                   (2, 2, 130, 800.0, False), (3, 3, 14, 90.0, True)])
 @pytest.mark.parametrize("remi", [False, True])
-def test_agent_steps_in_pairs_on_pathological_states(m, n, C, length, remi):
+def test_agent_steps_in_pairs_on_pathological_states(m, n, C, length, validate, remi):
     """tfx_agent_step over two-tick passes == tick by tick, from states where the first tick of a pair overflows
     rings, pops more than two cars per road or sends cars through a whole road (k_risk must sort those envs
     out: an env that overflows stands still for the rest of the step), and where the SECOND tick overflows (the
     env freezes with columns k_edge left uncompacted: the step's last launch moves them up)."""
     rng = np.random.RandomState(555 + C + int(remi))
     E = 12
-    a = pairs_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
-    c = pertick_engine(E, m=m, n=n, length=length, capacity=C, rate=0.5)
+    kw = dict(m=m, n=n, length=length, capacity=C, rate=0.5, validate=validate, planes=3 if validate else 2)
+    a = pairs_engine(E, **kw)
+    c = pertick_engine(E, **kw)
     froze = 0
     for trial, T in enumerate([3, 10, 4, 5, 10, 7]):
         x, v, w, leading, lastcar = random_state(rng, E, a.R, C, length, crowd=rng.choice([0.5, 0.9]),
@@ -228,16 +238,23 @@ def test_agent_steps_in_pairs_on_pathological_states(m, n, C, length, remi):
         period = int(rng.choice([1, 2, 5]))
         for eng in (a, c):
             eng.reset(phase)
-            eng.load_state(x, v, leading, lastcar)
+            eng.load_state(x, v, leading, lastcar, w=w if validate else None)
             eng.set_tick(40)
             eng.set_spawns(period=period)
             eng.set_actions(act)
+            if validate:
+                eng.n_trips.zero_()
         for step in range(3):      # (an env that overflowed simply goes on in the next step, as a caller that does not reset it would)
             ra = [t.clone() for t in a.agent_step(T, remi=remi)]
             rc = [t.clone() for t in c.agent_step(T, remi=remi)]
             for u, w_ in zip(ra, rc):
                 assert torch.equal(u, w_), (trial, step)
             assert_engines_equal(a, c)
+            if validate:
+                assert torch.equal(a.n_trips, c.n_trips), (trial, step)
+                for k in range(E):
+                    kk = min(int(a.n_trips[k]), a.trip_cap)
+                    assert torch.equal(a.trip_times[k, :kk], c.trip_times[k, :kk]), (trial, step, k)
             froze += int(ra[2].sum())
     assert a.pair_ticks() > 0 and c.pair_ticks() == 0 and froze > 0
 

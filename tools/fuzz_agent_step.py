@@ -25,8 +25,9 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))     # two-tick passes + k_risk forced at any size | never
     os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2])))         # (plain step() calls between decisions: k_tail, split)
     os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))
-    eng = TfxEngine(m, nn, L, C, n_envs=E, planes=2 if layout == "transposed" else 3, layout=layout)
-    orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts) for _ in range(E)]
+    val = bool(rng.randint(3) == 0)                               # validate mode: spawn ticks travel, trip times are logged
+    eng = TfxEngine(m, nn, L, C, n_envs=E, planes=3 if (val or layout != "transposed") else 2, layout=layout, validate=val)
+    orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts, validate=val) for _ in range(E)]
     ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
     eng.reset(ph)
     for k, o in enumerate(orcs):
@@ -49,6 +50,14 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
             live = live_mask(ld[k], lc[k], C)
             assert np.array_equal(xv[k][live][:, 0].view(np.int32), o.x[0][live].view(np.int32)), (n, step, k)
             assert np.array_equal(xv[k][live][:, 1].view(np.int32), o.v[0][live].view(np.int32)), (n, step, k)
+        if val:
+            w = eng.w.cpu().numpy()
+            nt = eng.n_trips.cpu().numpy()
+            for k, o in enumerate(orcs):
+                assert np.array_equal(w[k][live_mask(ld[k], lc[k], C)], o.w[0][live_mask(ld[k], lc[k], C)]), (n, step, k, "w")
+                assert nt[k] == o.n_trips[0], (n, step, k, "trips")
+                kk = min(int(nt[k]), eng.trip_cap)
+                assert np.array_equal(eng.trip_times[k, :kk].cpu().numpy(), o.trip_times[0, :kk]), (n, step, k, "trip times")
     n += 1
     del eng
 print("agent-step fuzz ok: %d cases, %d env-decisions ended by an overflow, %.0f s" % (n, early, time.time() - t0))

@@ -146,7 +146,8 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
 // One work item of the advance: s < I is intersection s of the env (its four incoming roads s, I+s, 2I+s, 3I+s,
 // roadgraph.py:38-39, plus the light words and the reward of that intersection), s >= I is exit road r + (s - I).
 // Item 0 of an env flagged for it runs the literal serial loop for the whole env.
-template <bool TL, bool HET = false, bool GREEDY = false>
+// WP = false: the caller knows there is no side-word plane (compact_head_rows)
+template <bool TL, bool HET = false, bool GREEDY = false, bool WP = true>
 __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int tick, int tidx) {
   const bool frozen = env_frozen(d, env, tick);  // stopped for the rest of this agent step
   const bool serial = !frozen && d.env_flag[env] == tick + 1;
@@ -159,7 +160,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
     return;
   }
   if (serial && s == 0) {
-    if (TL) advance_env_serial_t<HET>(d, env, tick, tidx);
+    if (TL) advance_env_serial_t<HET, WP>(d, env, tick, tidx);
     else advance_env_serial(d, env, tick, tidx);
     if (decide)
       for (int i = 0; i < d.I; ++i) d.greedy_act[(size_t)env * d.I + i] = greedy_decide(d, env, i);
@@ -172,7 +173,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
 #pragma unroll
       for (int dir = 0; dir < 4; ++dir) {
         const int e = dir * d.I + s;
-        ovf += (TL ? advance_road_t<HET>(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
+        ovf += (TL ? advance_road_t<HET, WP>(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
       }
       // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
       float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
     ob[d.I + s] = el_new;
   } else if (!serial) {
     const int e = d.r + (s - d.I);
-    const int ovf = TL ? advance_road_t<HET>(d, env, e) : advance_road(d, env, e, tick, tidx);
+    const int ovf = TL ? advance_road_t<HET, WP>(d, env, e) : advance_road(d, env, e, tick, tidx);
     if (ovf > 0) d.done_tick[env] = tick + 1;
     if (d.validate && d.n_trips && s == d.I) {
       // advance_hack :153-154: trip times of cars leaving the map, in road order

@@ -15,12 +15,18 @@ namespace tfx {
 
 // A column whose live rows start `hb` rows down (left so by k_edge) has room for only trows - hb cars: before a
 // push would run past the tile's last row, move the n physical cars up to row 0 and clear the offset.
+// WP = false: the caller knows the handle has no side-word plane (k_tail<.., W = false>: the rare copy costs it two
+// registers, and with them a wavefront per SIMD)
+template <bool WP = true>
 __device__ __forceinline__ void compact_head_rows(const Dev &d, int id, int hb, int n) {
-  for (int q = 0; q < n; ++q) d.xv[tpos(d, id, q)] = d.xv[tpos(d, id, q + hb)];  // (never in validate mode: no w plane)
+  for (int q = 0; q < n; ++q) {
+    d.xv[tpos(d, id, q)] = d.xv[tpos(d, id, q + hb)];
+    if (WP && d.w) d.w[tpos(d, id, q)] = d.w[tpos(d, id, q + hb)];
+  }
   d.rec[id].y &= ~(3 << 28);
 }
 
-template <bool HET = false>
+template <bool HET = false, bool WP = true>
 __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   const int C = d.C;
   const int id = env * d.R + e;
@@ -41,7 +47,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
     if (k_p > 0) {
       int hb = rec_hb(rc.y);
       if (hb > 0 && hb + m + k_p > d.trows) {
-        compact_head_rows(d, id, hb, m);
+        compact_head_rows<WP>(d, id, hb, m);
         hb = 0;
       }
       m += hb;  // first free row
@@ -88,7 +94,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
 //                                 kpop, i.e. compacted.
 // (inlined on purpose: as a real call it took no SGPR spills but a 512-byte stack frame per lane for the parameter
 // block, and k_tail went from 0.19 to 0.43 ms per pair)
-template <bool HET = false>
+template <bool HET = false, bool WP = true>
 __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) {
   const int C = d.C;
   int *ob = d.obs + (size_t)env * d.obs_len;
@@ -142,7 +148,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int ta = HET ? d.taila[idn] : 0;
     const float tl = HET ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = HET ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
     const float start = (lcn != ldn) ? (d.tailx[idn] - tl) - ts0 : INFINITY;
-    if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
+    if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows<WP>(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
     if (pos != ldn) {
       const float xv = (start < car.x) ? start : car.x;
       d.xv[rowb(idn, base + phys)] = make_float2(xv, car.y);

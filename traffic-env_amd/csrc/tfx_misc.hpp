@@ -51,8 +51,9 @@ __global__ void k_refresh(const Dev d) {
       d.tailx[id] = d.xv[(size_t)id * d.C + d.lastcar[id]].x;
     } else {
       const int n = ring_count(d.leading[id], d.lastcar[id], d.C);
-      d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1 + rec_hb(d.rec[id].y))].x : 0.0f;
-      if (d.het) d.taila[id] = (n > 0) ? side_arch(d.w[tpos(d, (int)id, n - 1)]) : 0;
+      const int hb = rec_hb(d.rec[id].y);
+      d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1 + hb)].x : 0.0f;
+      if (d.het) d.taila[id] = (n > 0) ? side_arch(d.w[tpos(d, (int)id, n - 1 + hb)]) : 0;
     }
   }
 }
@@ -72,7 +73,7 @@ __global__ void k_export_ring(const Dev d, float2 *ring, float *ringw, uint8_t *
       slot = wrap1(slot + 1, d.C);
       row[slot] = d.xv[tpos(d, (int)id, k + hb)];
       if (d.w && (ringw || ringa)) {  // (heterogeneous cars: the side word is 8 * spawn tick + table row)
-        const float sw = d.w[tpos(d, (int)id, k)];
+        const float sw = d.w[tpos(d, (int)id, k + hb)];
         if (ringw) ringw[(size_t)id * d.C + slot] = side_tick(d, sw);
         if (ringa) ringa[(size_t)id * d.C + slot] = d.het ? (uint8_t)side_arch(sw) : 0;
       }

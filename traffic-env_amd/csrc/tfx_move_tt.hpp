@@ -58,9 +58,14 @@ namespace tfx {
 #ifndef TT_WAVES
 #define TT_WAVES 6
 #endif
-#define TT_ATTR __attribute__((amdgpu_waves_per_eu(TT_WAVES, TT_WAVES)))
-template <bool TWO, bool AGENT = false>
-__global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int tidx, const int only_risky) {
+#ifndef TT_WAVES_W
+#define TT_WAVES_W 4
+#endif
+#define TT_ATTR(W) __attribute__((amdgpu_waves_per_eu((W) ? TT_WAVES_W : TT_WAVES, (W) ? TT_WAVES_W : TT_WAVES)))
+// W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157): a car's side word
+// is stored wherever its (x, v) is
+template <bool TWO, bool AGENT = false, bool W = false>
+__global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
   constexpr int P = TT_P;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -95,6 +100,8 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
     float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;  // written: row k of this road = col[k * 64]
     const float2 *colr = col + (size_t)hb * 64;                 // read: the live rows start hb rows down
     float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+    float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;  // side words: same rows as col
+    float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
     int kmax = n_old;
 #pragma unroll
@@ -106,6 +113,7 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
 
     float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
     float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
+    float y1w = 0.0f;                                      // side word of car k-1
     int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
     bool open = true, far = false;
     bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
     };
     // Car k of this lane's road through tick t, car k-1 through tick t+1.  `last` (a compile-time flag): only
     // the second half, for the road's last car.
-    auto step = [&](int k, float x, float v, auto last) {
+    auto step = [&](int k, float x, float v, float sw, auto last) {
       constexpr bool LAST = decltype(last)::value;
       float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
       // (one wave-wide test per row.  Round 3 measured the alternatives on this kernel: the speeds read from memory
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
       }
       if (TWO && two && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
         st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
+        if (W) wcol[wp - col] = y1w;
         wp += 64;
         if (pend_int) {
           const float wq1 = (k - 1 >= kq1) ? zx : zv;
@@ -160,8 +169,10 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
       if (pop) {
         if (kpop < KP) {
           ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+          if (W) owcol[(size_t)kpop * 64] = sw;
         } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
           st2(&col[(size_t)k * 64], xn, vn);
+          if (W) wcol[(size_t)k * 64] = sw;
           wp = col + (size_t)(k + 1) * 64;
         }
         far = far || ((xn - d.length) > d.length);
@@ -172,6 +183,7 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
         if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
       } else {
         st2(wp, xn, vn);
+        if (W) wcol[wp - col] = sw;
         wp += 64;
       }
       const float wq = (k >= kq) ? xn : vn;
@@ -182,20 +194,30 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
       y2v = y1v;
       y1x = xn;
       y1v = vn;
+      if (W) y1w = sw;
     };
 
     // ---- cars in memory: rows 0 .. kmax-1 of the live part, P rows in flight --------------------
     float2 pf[P];
+    float pfw[P];
+    const float *wcolr = wcol + (size_t)hb * 64;
 #pragma unroll
-    for (int u = 0; u < P; ++u) pf[u] = (u < n_old) ? ld2(&colr[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+    for (int u = 0; u < P; ++u) {
+      pf[u] = (u < n_old) ? ld2(&colr[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+      pfw[u] = (W && u < n_old) ? wcolr[(size_t)u * 64] : 0.0f;
+    }
     for (int k0 = 0; k0 < kmax; k0 += P) {
 #pragma unroll
       for (int u = 0; u < P; ++u) {
         const int k = k0 + u;
         if (k < kmax) {
           const float2 cur = pf[u];
-          if (k + P < kmax) pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
-          if (k < n_old) step(k, cur.x, cur.y, std::false_type{});
+          const float curw = pfw[u];
+          if (k + P < kmax) {
+            pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+            pfw[u] = (W && k + P < n_old) ? wcolr[(size_t)(k + P) * 64] : 0.0f;
+          }
+          if (k < n_old) step(k, cur.x, cur.y, curw, std::false_type{});
         }
       }
     }
@@ -209,11 +231,11 @@ __global__ __launch_bounds__(256) TT_ATTR void k_move_tt(const Dev d, const int 
       }
       smax = __builtin_amdgcn_readfirstlane(smax);
       for (int s = 0; s < smax; ++s)
-        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, std::false_type{});
+        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick, std::false_type{});
     }
     // ---- the road's last car through tick t+1 ----------------------------------------------------
     if (TWO && two && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
-      if (pend) step(p.n_tot, 0.0f, 0.0f, std::true_type{});
+      if (pend) step(p.n_tot, 0.0f, 0.0f, 0.0f, std::true_type{});
     }
 
     // ---- phase W -------------------------------------------------------------------------------
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
 // The second tick of a pair for the cars k_move_tt<true> could not take through it (see the head of this
 // file), for the 64 roads of one tile: lane = road.  Runs after the advance of the first tick; same tile / lane
 // ownership as the pass, a few cars per road.  Returns the lane's vehicle-updates.
-template <bool AGENT>
+template <bool AGENT, bool W = false>
 __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx) {
   const int C = d.C;
   // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
@@ -308,6 +330,8 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
 
   float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;
   float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+  float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
+  float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
   // r2.y: the road's waiting count of the first tick plus the second tick's so far; r2.z: detected so far
   int kpop = 0, n_wait = r2.y, n_det = r2.z;
@@ -315,8 +339,8 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   const int kq = C - 1 - p.ld;
   float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
   float tail_x = 0.0f;
-  // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll)
-  auto car = [&](int i, float x, float v) {
+  // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll); fresh: spawned this tick
+  auto car = [&](int i, float x, float v, bool fresh) {
     float zx, zv;
     idm_step(d, x, v, lx, lv, ll, zx, zv);
     lx = x;
@@ -324,8 +348,13 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     ll = d.car_l;
     const bool pop = open && (zx > d.length);
     open = pop;
-    if (pop && kpop < KP) ocol[(size_t)kpop * 64] = make_float2(zx, zv);
-    else col[(size_t)i * 64] = make_float2(zx, zv);  // (a popped car beyond the outbox stays in its row: uncompacted)
+    if (pop && kpop < KP) {
+      ocol[(size_t)kpop * 64] = make_float2(zx, zv);
+      if (W) owcol[(size_t)kpop * 64] = fresh ? (float)tick : wcol[(size_t)i * 64];
+    } else {  // (a popped car beyond the outbox stays in its row: uncompacted)
+      col[(size_t)i * 64] = make_float2(zx, zv);
+      if (W && fresh) wcol[(size_t)i * 64] = (float)tick;
+    }
     if (pop) far = far || ((zx - d.length) > d.length);
     kpop += pop ? 1 : 0;
     const float wq = (i >= kq) ? zx : zv;
@@ -335,12 +364,15 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   };
   if (m0 > 0) {
     const float2 head = col[0];
-    car(0, head.x, head.y);
+    car(0, head.x, head.y, false);
     // cars behind a head that left: already a tick ahead, the pop prefix may run on into them
     for (int i = 1; i < m0 && open; ++i) {
       const float2 z = col[(size_t)i * 64];
       if (z.x > d.length) {
-        if (kpop < KP) ocol[(size_t)kpop * 64] = z;
+        if (kpop < KP) {
+          ocol[(size_t)kpop * 64] = z;
+          if (W) owcol[(size_t)kpop * 64] = wcol[(size_t)i * 64];
+        }
         far = far || ((z.x - d.length) > d.length);
         ++kpop;
       } else {
@@ -355,9 +387,9 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   }
   for (int i = m0; i < n_old; ++i) {  // handed over by the first tick's advance
     const float2 c = col[(size_t)i * 64];
-    car(i, c.x, c.y);
+    car(i, c.x, c.y, false);
   }
-  for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v);  // spawned this tick
+  for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v, true);  // spawned this tick
 
   const bool unc = kpop > KP;
   if (e < d.r) {
@@ -374,7 +406,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   return n_tot;
 }
 
-template <bool AGENT>
+template <bool AGENT, bool W = false>
 __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -385,7 +417,7 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
 
   unsigned long long my_updates = 0;
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw)
-    my_updates += (unsigned long long)edge_tile<AGENT>(d, tile, (int)(tile / d.G), lane, tick, tick_sp, tidx);
+    my_updates += (unsigned long long)edge_tile<AGENT, W>(d, tile, (int)(tile / d.G), lane, tick, tick_sp, tidx);
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if (lane == 0 && my_updates) veh_add(d.veh, my_updates);

@@ -27,7 +27,8 @@ namespace tfx {
 // marked for this pair (env_risk == t + 1: their first tick could overflow, so the pass took them through ONE tick) get
 // the advance of tick t here and their whole second tick from the two restricted launches that follow
 // (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).
-template <bool GREEDY = false, bool AGENT = false>
+// W: validate mode - the cars' side words travel along (edge_tile)
+template <bool GREEDY = false, bool AGENT = false, bool W = false>
 __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -38,13 +39,13 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY>(d, env, s, tick, tidx);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY, W>(d, env, s, tick, tidx);
     if (AGENT && d.env_risk[env] == tick + 1) continue;  // (workgroup-uniform; nobody waits at a barrier for it)
     __syncthreads();
     for (int g = wv; g < d.G; g += nwv)
-      my_updates += (unsigned long long)edge_tile<AGENT>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1);
+      my_updates += (unsigned long long)edge_tile<AGENT, W>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1);
     __syncthreads();
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY>(d, env, s, tick + 1, tidx + 1);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY, W>(d, env, s, tick + 1, tidx + 1);
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);

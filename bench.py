@@ -287,6 +287,12 @@ def main():
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--stream-priority", type=int, default=None,
+                    help="run the ticks on a torch stream of this priority (-1 = high; the default with a process "
+                         "group) instead of the default stream")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="N = 1 with everything a rank of an N > 1 run does: an RCCL process group (of one rank), the "
+                         "snapshot + gather every %d ticks, barriers and reductions" % GATHER_EVERY)
     ap.add_argument("--no-numpy-baseline", action="store_true")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed ticks run right after the prefill, as part of the workload's setup and before the W "
@@ -320,13 +326,25 @@ def main():
     local = 0 if rehearsal else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or a.rccl_one_rank
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    # With a process group the ticks run on a HIGH-priority stream (the handle's second stream is then a low-priority
+    # one): HIP shares its hardware queues among the streams of one priority level, and RCCL's own streams and
+    # torch's pool are of normal priority - a collective kernel that waits for its peers must never sit in the
+    # hardware queue the car passes go through.
+    prio = a.stream_priority if a.stream_priority is not None else (-1 if dist_on else None)
+    if prio is not None:
+        torch.cuda.set_stream(torch.cuda.Stream(device, priority=prio))
     c = wl.CONFIGS[a.config]
     E = int(a.envs if a.envs is not None else c["envs"])
     eng = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
@@ -341,8 +359,8 @@ def main():
         eng.step(settle % 50)
     torch.cuda.synchronize(device)
     gather = None
-    if world > 1 and not a.no_gather:
-        gather = RolloutGather(E, eng.obs_len, eng.I, device)
+    if dist_on and not a.no_gather:
+        gather = RolloutGather(E, eng.obs_len, eng.I, device, single_rank_collective=a.rccl_one_rank)
 
     chunk = GATHER_EVERY if gather is not None else (a.call_ticks if a.call_ticks > 0 else 1 << 30)
 
@@ -359,7 +377,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -391,7 +409,7 @@ def main():
     red_dev = torch.device("cpu") if rehearsal else device
     tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     uu = torch.tensor([updates], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
     dt_max, total_updates = float(tt.item()), float(uu.item())
@@ -432,7 +450,7 @@ def main():
             if not a.no_numpy_baseline:
                 out["cpu_baseline"]["numpy_batched_one_core"] = numpy_baseline(a.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

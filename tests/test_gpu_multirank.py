@@ -129,6 +129,48 @@ def _rccl_rank(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _rccl_single_rank(rank, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        from gym_traffic import workload as wl
+        from gym_traffic.distributed import RolloutGather
+        eng = wl.setup_engine("cfg2", device=device, envs=96)
+        gather = RolloutGather(96, eng.obs_len, eng.I, device, single_rank_collective=True)
+        assert gather.stage_dev == device and gather.collect
+        snaps = []
+        for _ in range(5):
+            eng.step(10)
+            snaps.append([t.clone() for t in (eng.obs, eng.rewards, eng.done)])
+            gather.start(eng.obs, eng.rewards, eng.done)
+            eng.step(3)                                            # ticks run on while the gather is in flight
+            got = gather.result()
+            for a, b in zip(got, snaps[-1]):
+                assert torch.equal(a, b)
+        t = torch.tensor([3.5], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        np.savez(os.path.join(out_dir, "one.npz"), collectives=gather.collectives, t=t.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_process_group_of_one_rank(tmp_path):
+    """The `nccl` branch of RolloutGather and of bench.py on a one-GPU box: an RCCL communicator of one rank, the
+    gather issued on the side stream through RCCL for real (single_rank_collective), work handles, barrier,
+    float64 reductions - everything but a second device."""
+    mp.spawn(_rccl_single_rank, args=(free_port(), str(tmp_path)), nprocs=1, join=True)
+    z = np.load(os.path.join(str(tmp_path), "one.npz"))
+    assert int(z["collectives"]) == 5 and float(z["t"][0]) == 3.5
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (this box has one)")
 def test_two_gpus_rccl_gather_equals_one_process(tmp_path):
     """cfg3's code path for real: one rank per GPU, backend nccl (= RCCL over xGMI), uneven shards (151 + 150 envs,

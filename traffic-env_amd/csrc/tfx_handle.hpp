@@ -55,6 +55,7 @@ struct tfx_handle_s {
   // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)
   int split = 1;              // TFX_SPLIT=0 never, 2 at any batch size
   hipStream_t split_stream = nullptr;
+  int split_prio = 0;  // priority level split_stream was created with
   hipEvent_t split_fork = nullptr, split_join = nullptr, split_stagger = nullptr;
   // which half of a split call is being enqueued (-1: none) and whether its first pass is still to come: the second
   // half's first pass waits for the first half's (from then on a half's pass runs under the other half's k_tail; left to

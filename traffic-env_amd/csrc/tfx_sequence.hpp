@@ -5,10 +5,27 @@
 
 namespace {
 
-// the second stream of a split call and the events that fork it from / join it to the caller's stream
-int ensure_split(tfx_handle h) {
-  if (h->split_stream) return TFX_OK;
-  HIPCHK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+// the second stream of a split call and the events that fork it from / join it to the caller's stream.
+// The second stream must not share a hardware queue with the caller's: HIP hands its hardware queues (4 per priority
+// level by default) to streams as they are created and shares them from then on, and two streams on one queue run
+// their kernels in order - no overlap.  Measured at cfg2 in a process that had initialised RCCL before the handle's
+// first split call (as every rank of `bench.py --gpus N` does): a plain second stream 4.43-4.47e11 vehicle-updates/s
+// against 5.1-5.2e11 without RCCL; a second stream of ANOTHER priority level - its own pool of queues - 5.10-5.11e11
+// either way (low priority: 4.91e11; a CU-masked stream: 4.43e11 either way).
+int ensure_split(tfx_handle h, hipStream_t caller) {
+  int lo = 0, hi = 0, cp = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (numerically: hi <= 0 <= lo)
+  if (hipStreamGetPriority(caller, &cp) != hipSuccess) cp = 0;
+  const int want = (cp == hi) ? lo : hi;   // high priority; low if high is the caller's own level
+  if (h->split_stream && h->split_prio == want) return TFX_OK;
+  if (h->split_stream) {
+    HIPCHK(hipStreamSynchronize(h->split_stream));
+    HIPCHK(hipStreamDestroy(h->split_stream));
+    h->split_stream = nullptr;
+  }
+  HIPCHK(hipStreamCreateWithPriority(&h->split_stream, hipStreamNonBlocking, want));
+  h->split_prio = want;
+  if (h->split_fork) return TFX_OK;
   HIPCHK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->split_stagger, hipEventDisableTiming));
@@ -177,7 +194,7 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
 int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
-    if (int rc = ensure_split(h)) return rc;
+    if (int rc = ensure_split(h, st)) return rc;
     if (h->grid_tt[1] == 0 || h->grid_tt[0] == 0 || h->grid_tail == 0) {  // grids are sized for the whole range
       h->size_only = true;
       (void)launch_move_tt<true>(h, 0, nullptr);

@@ -26,10 +26,14 @@ class RolloutGather(object):
 
     DEPTH = 2
 
-    def __init__(self, n_local, obs_len, n_intersections, device, dst=0, group=None, counts=None):
+    def __init__(self, n_local, obs_len, n_intersections, device, dst=0, group=None, counts=None,
+                 single_rank_collective=False):
         """counts: envs per rank when the shards differ (`[hi - lo for lo, hi in (shard_range(total, r,
         world) ...)]` - a pure function of the sharding, so no exchange is needed); default: every
-        rank holds n_local envs."""
+        rank holds n_local envs.
+        single_rank_collective: issue the gather even in a process group of ONE rank (by default a single
+        rank gathers nothing) - runs the backend's whole path (RCCL: communicator, side stream, work
+        handles) on a one-GPU box."""
         self.dst, self.group = dst, group
         on = dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -50,7 +54,8 @@ class RolloutGather(object):
         pin = self.stage_dev.type == "cpu" and self.device.type == "cuda"
         self.snap = [self._buf(pin) for _ in range(self.DEPTH)]
         self.recv = None
-        if self.rank == dst and self.world > 1:
+        self.collect = self.world > 1 or (on and bool(single_rank_collective))
+        if self.rank == dst and self.collect:
             self.recv = [[self._buf(False) for _ in range(self.world)] for _ in range(self.DEPTH)]
         self.side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.pending = [None] * self.DEPTH
@@ -91,7 +96,7 @@ class RolloutGather(object):
         else:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             ctx = torch.cuda.stream(self.side)
-        if self.world > 1:
+        if self.collect:
             with ctx:
                 self.pending[k] = dist.gather(snap, self.recv[k] if self.rank == self.dst else None,
                                               dst=self.dst, group=self.group, async_op=True)
@@ -109,7 +114,7 @@ class RolloutGather(object):
         env-id order; None on the other ranks."""
         self.wait()
         k = (self.started - 1) % self.DEPTH
-        if self.world == 1:
+        if not self.collect:
             parts, counts = [self.snap[k]], [self.n]
         elif self.rank != self.dst:
             return None

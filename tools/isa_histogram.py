@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction-class histogram of a kernel's inner loop from the compiler's own ISA (make -C traffic-env_amd/csrc asm).
 
-  tools/isa_histogram.py [--kernel _ZN3tfx9k_move_ttILb1ELb0EEEvNS_3DevEii] [--rows 3.34e6]
+  tools/isa_histogram.py [--kernel _ZN3tfx9k_move_ttILb1ELb0ELb0EEEvNS_3DevEii] [--rows 3.34e6]
 
 Takes every basic block the compiler marks as part of a depth-2 loop of the kernel (the walk over the rows of a tile,
 unrolled P = 4 times), drops the blocks of the literal-division fallback (they hold three IEEE division expansions; the
@@ -36,7 +36,7 @@ CLASSES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="_ZN3tfx9k_move_ttILb1ELb0EEEvNS_3DevEii")
+    ap.add_argument("--kernel", default="_ZN3tfx9k_move_ttILb1ELb0ELb0EEEvNS_3DevEii")
     ap.add_argument("--rows", type=float, default=4096 * 17 * 47.45, help="row-iterations per launch (cfg2: tiles x mean road length)")
     ap.add_argument("--unroll", type=int, default=4)
     a = ap.parse_args()

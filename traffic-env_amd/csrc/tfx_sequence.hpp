@@ -65,10 +65,13 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     (void)launch_advance(h, 0, nullptr);
     h->size_only = false;
     (void)edge_grid(h);
+    // (the second half's clock is copied on the CALLER's stream, ahead of the fork: copied on the second stream it
+    // raced with the first half's kernels, which move the clock on - a new stream's first launch can take longer to
+    // start than a small batch's whole pair)
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, st, whole.tickA, whole.tickB, h->tick2);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->split_fork, st));
     HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
-    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
-    HIPCHK(hipGetLastError());
   }
   hipStream_t user_st = st;
   for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
@@ -206,10 +209,11 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
     const Dev whole = h->d;
     const int n0 = whole.E / 2;
     const long long pair0 = h->pair_ticks, tail0 = h->tail_ticks;
+    // (the clock copy runs on the caller's stream, ahead of the fork: see agent_sequence)
+    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, st, whole.tickA, whole.tickB, h->tick2);
+    int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
     HIPCHK(hipEventRecord(h->split_fork, st));
     HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
-    hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, h->split_stream, whole.tickA, whole.tickB, h->tick2);
-    int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
     for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
       h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
       h->split_half = half;

@@ -52,4 +52,9 @@ python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-base
 ( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt
 ( python3 tools/run_cfg4.py; python3 tools/c4_quick.py ) 2>&1 | grep -v amdgpu.ids > $O/cfg4_closed_loop.txt
 ( python3 tools/bench_agent_step.py cfg2; TFX_PAIRS=0 python3 tools/bench_agent_step.py cfg2 ) 2>&1 | grep -v amdgpu.ids > $O/agent_step_cfg2.txt
+# the driver's short run, with and without the workload's settle ticks; one rank with everything a rank of an N > 1 run does
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg2_20steps.json 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 --settle 0 --no-cpu-baseline > $O/bench_cfg2_20steps_nosettle.json 2>/dev/null
+python3 bench.py --rccl-one-rank --no-cpu-baseline > $O/bench_cfg2_rccl_one_rank.json 2>/dev/null
+( python3 tools/bench_validate.py; TFX_PAIRS=0 python3 tools/bench_validate.py; python3 tools/bench_archetypes.py ) 2>&1 | grep -v amdgpu.ids > $O/validate_and_archetypes_cfg2.txt
 echo finished

@@ -112,11 +112,12 @@ def main():
                   # why x2 holds for THIS kernel's 8-byte-per-lane row loads and not only for the guide's 16-byte
                   # ones: the launch reads every live car once (16 N_live... 8 B each) and the raw counter comes out
                   # at half of that
-                  "correction_basis": "the kernel's read side is known exactly - 8 B per live car + the per-road words "
-                                      "- and FETCH_SIZE x 1024 comes out at %.3f of it; a stream of KNOWN size (tools/fetch_factor.sh "
-                                      "over tools/copy_probe.hip, 8 and 16 bytes per lane) reads 0.500 x its bytes on "
-                                      "FETCH_SIZE and 1.000 x on WRITE_SIZE (profiles/r03_fetch_size_factor.txt)" % (a.read_bytes_expected and
-                                      fetch * 1024 / a.read_bytes_expected or float("nan")),
+                  "correction_basis": (("the kernel's read side is known exactly - 8 B per live car + the per-road words "
+                                        "- and FETCH_SIZE x 1024 comes out at %.3f of it; " % (fetch * 1024 / a.read_bytes_expected))
+                                       if a.read_bytes_expected else "") +
+                                      "a stream of KNOWN size (tools/fetch_factor.sh over tools/copy_probe.hip, 8 and 16 bytes per "
+                                      "lane) reads 0.500 x its bytes on FETCH_SIZE and 1.000 x on WRITE_SIZE "
+                                      "(profiles/r03_fetch_size_factor.txt)",
                   "note": a.note}
             if (mv, "SQ_INSTS_VALU") in agg:
                 v = med(agg[(mv, "SQ_INSTS_VALU")])

@@ -197,6 +197,22 @@ def numpy_baseline(name, budget_s=8.0):
     return time_config(name, budget_s)
 
 
+class stdout_to_stderr(object):
+    """File descriptor 1 -> stderr for the duration (native libraries write to the descriptor, not to sys.stdout)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -336,7 +352,11 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=device)
+            # RCCL prints a version banner on STDOUT when its communicator comes up: stdout carries the one JSON line and
+            # nothing else, so file descriptor 1 points at stderr until the communicator exists
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", device_id=device)
+                dist.barrier()
 
     # With a process group the ticks run on a HIGH-priority stream (the handle's second stream is then a low-priority
     # one): HIP shares its hardware queues among the streams of one priority level, and RCCL's own streams and

@@ -151,6 +151,39 @@ def test_pairs_golden_ints(golden_cache):
     assert t == 120 and eng.pair_ticks() > 80
 
 
+def test_pairs_golden_validate_trip_times(golden_cache):
+    """The reference's validate-mode run (advance_hack's trip times, traffic_env.py:139-157) through the W forms of the
+    pairs: the trip log equals the oracle's for the whole 400-tick run, and the reference's own over the first 120 ticks."""
+    g = golden_cache("g2x2_validate")
+    sc = g.sc
+    eng = pairs_engine(1, m=sc["m"], n=sc["n"], length=sc["L"], capacity=sc["C"], rate=sc["rate"], validate=True, planes=3)
+    orc = oracle_like(eng)
+    eng.reset(g["init_phase"])
+    orc.reset(g["init_phase"])
+    T = len(g["actions"])
+    t = 0
+    for chunk in [2, 9, 4, 16, 3, 10, 10, 7, 25, 6, 8, 20, 51, 50, 50, 50, 50, 29]:
+        chunk = min(chunk, T - t)
+        if chunk <= 0:
+            break
+        acts = g["actions"][t:t + chunk][:, None, :]
+        sp = np.stack([counts(eng, [g.spawns(t + j)]) for j in range(chunk)])
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=sp, per_tick=True)
+        eng.step(chunk)
+        for j in range(chunk):
+            orc.step(g["actions"][t + j], [g.spawns(t + j)])
+        t += chunk
+        assert_same_state(eng, orc, "tick %d" % t)
+        if t == 120:        # (the horizon over which every fixture's integers are held to the reference's)
+            n = int(g["trip_count"][120])
+            assert int(eng.n_trips[0]) == n
+            assert np.array_equal(eng.trip_times[0, :n].cpu().numpy().astype(np.float64), g["trip_times"][:n])
+    n = int(eng.n_trips[0])
+    assert t == T and n == int(orc.n_trips[0]) and n > 10 and eng.pair_ticks() > 300
+    assert np.array_equal(eng.trip_times[0, :n].cpu().numpy(), orc.trip_times[0, :n])
+
+
 def test_pairs_with_device_poisson_and_greedy():
     """On-device Poisson arrivals and the greedy controller produce the second tick's inputs between the two
     halves of a pair: same streams, same lights, same cars as tick by tick."""

@@ -25,14 +25,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t", "k_move")
 
 
+def _code_only(text):
+    """C++ source without comments and blank lines (string literals kept intact)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(l.rstrip() for l in "".join(out).split("\n") if l.strip())
+
+
 def csrc_hash():
-    """sha256 over the kernel sources and the ABI header (sorted by name), first 16 hex digits."""
+    """sha256 over the kernel sources and the ABI header (sorted by name) with comments and blank lines removed - an
+    edited comment does not unpin the profiles, an edited statement does; first 16 hex digits."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "traffic-env_amd", "csrc")
     files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".hip", ".cpp")))
     for f in files + [os.path.join(ROOT, "include", "tfx.h")]:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -13,8 +13,8 @@ torch = pytest.importorskip("torch")
 from gym_traffic import workload as wl  # noqa: E402
 
 
-def oracle_for(eng, c, envs, first_env):
-    orc = OracleEnv(c["m"], c["n"], c["length"], c["capacity"], eng.dest, eng.phases, eng.nexts, n_envs=envs)
+def oracle_for(eng, c, envs, first_env, validate=False):
+    orc = OracleEnv(c["m"], c["n"], c["length"], c["capacity"], eng.dest, eng.phases, eng.nexts, n_envs=envs, validate=validate)
     orc.reset(np.zeros(orc.I, np.int32))
     x, v, leading, lastcar = wl.prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
     for k in range(envs):
@@ -113,6 +113,36 @@ def test_cfg2_full_size_two_tick_passes_vs_oracle():
     for j in range(3):
         live = live_mask(lds[j], lcs[j], C)
         assert np.array_equal(small.x[j].cpu().numpy()[live].view(np.int32), eng.x[2047 + j].cpu().numpy()[live].view(np.int32))
+
+
+def test_cfg2_full_size_validate_mode_in_pairs_vs_oracle():
+    """Validate mode at the headline size: the spawn-tick plane through the W forms of the pass and of k_tail, both halves
+    of the split; sampled envs equal the oracle in every integer, every live car's x / v / w and the trip log."""
+    c = wl.CONFIGS["cfg2"]
+    eng = wl.setup_engine("cfg2", validate=True)
+    C = eng.C
+    sample = [0, 2047, 2048, 4095]
+    orcs = [oracle_for(eng, c, 1, k, validate=True) for k in sample]
+    t = 0
+    for chunk in [2, 9, 12, 1, 16]:
+        eng.step(chunk)
+        for _ in range(chunk):
+            for (orc, ids) in orcs:
+                step_oracle(orc, ids, eng, t, threads=1)
+            t += 1
+    assert eng.pair_ticks() == 2 + 8 + 12 + 16 and eng.tail_ticks() == eng.pair_ticks() and eng.split_ticks() == 2 + 9 + 12 + 16
+    ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+    nt = eng.n_trips.cpu().numpy()
+    assert int(nt.sum()) > 4096 * 10
+    for (orc, ids), k in zip(orcs, sample):
+        assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), k
+        assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]) and np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), k
+        live = live_mask(ld[k], lc[k], C)
+        for got, want in ((eng.x[k], orc.x[0]), (eng.v[k], orc.v[0]), (eng.w[k], orc.w[0])):
+            assert np.array_equal(got.cpu().numpy()[live].view(np.int32), want[live].view(np.int32)), k
+        n = int(nt[k])
+        assert n == int(orc.n_trips[0]) and 0 < n <= eng.trip_cap
+        assert np.array_equal(eng.trip_times[k, :n].cpu().numpy(), orc.trip_times[0, :n]), k
 
 
 @pytest.mark.parametrize("layout", ["ring", "transposed"])

@@ -73,14 +73,15 @@ def algorithmic_bytes_per_tick(live_cars, roads, intersections):
     return 16 * live_cars + 48 * roads + 32 * intersections
 
 
-def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2, layout=None):
-    """A TfxEngine for config `name`, prefilled and switched to the on-device spawn/light rules."""
+def setup_engine(name, device=None, envs=None, env_id_offset=0, planes=2, layout=None, validate=False, trip_cap=4096):
+    """A TfxEngine for config `name`, prefilled and switched to the on-device spawn/light rules.
+    validate: the reference's `--mode validate` (cars carry their spawn tick, trip times are logged)."""
     import torch
     from gym_traffic.core import TfxEngine
     c = CONFIGS[name]
     E = int(envs if envs is not None else c["envs"])
-    eng = TfxEngine(c["m"], c["n"], c["length"], c["capacity"], n_envs=E, rate=0.5, planes=planes,
-                    device=device, env_id_offset=env_id_offset, layout=layout)
+    eng = TfxEngine(c["m"], c["n"], c["length"], c["capacity"], n_envs=E, rate=0.5, planes=3 if validate else planes,
+                    device=device, env_id_offset=env_id_offset, layout=layout, validate=validate, trip_cap=trip_cap)
     eng.reset(np.zeros((1, eng.I), np.int32))
     x, v, leading, lastcar = prefill_one_env(c["m"], c["n"], c["length"], c["capacity"], c["prefill"], c["gap"])
     dev = eng.device

@@ -168,6 +168,112 @@ def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
                 assert np.array_equal(eng.trip_times[k, :nt[k]].cpu().numpy(), orc.trip_times[k, :nt[k]])
 
 
+@pytest.mark.parametrize("tail,split", [("2", "0"), ("0", "0"), ("2", "2")])
+@pytest.mark.parametrize("C,validate", [(10, False), (34, True), (66, False)])
+def test_mixed_rows_in_two_tick_pairs_vs_oracle(C, validate, tail, split):
+    """The same pathological states through multi-tick calls: the HET forms of the two-tick pass, of k_edge / k_tail and
+    the two-stream split (forced at test size).  A car's own row drives BOTH of its ticks in the pass, its leader's row
+    the gap; arrivals of mixed rows come from per-tick count and row buffers."""
+    from test_gpu_fused import engine_with
+    from test_gpu_parity import random_state
+    tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
+                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
+    tab10 = np.zeros((4, 10), np.float32)
+    tab10[:, ROWS] = tab8
+    m, n, L, E = 3, 2, 150.0, 5
+    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": tail, "TFX_SPLIT": split}, E, planes=3,
+                      m=m, n=n, length=L, capacity=C, validate=validate, archetypes=tab8)
+    orc = OracleEnv(m, n, L, C, eng.dest, eng.phases, eng.nexts, n_envs=E, validate=validate)
+    rng = np.random.RandomState(4100 + C)
+    ran = 0
+    for trial, T in enumerate([2, 5, 4, 7, 3, 6]):
+        x, v, w, leading, lastcar = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.3, 0.8]),
+                                                 beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=bool(trial % 2))
+        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
+        eng.reset(phase)
+        orc.reset(phase)
+        eng.load_state(x, v, leading, lastcar, w=w, arch=arch)
+        for k in range(E):
+            orc.load_planes(k, x[k], v[k], w[k], leading[k], lastcar[k], arch=arch[k], archetypes=tab10)
+        eng.set_tick(60)
+        orc.steps[:] = 60
+        acts = rng.randint(2, size=(T, E, eng.I)).astype(np.int32)
+        roads = [[rng.choice(eng.entrypoints, size=rng.randint(0, 4)).tolist() for _ in range(E)] for _ in range(T)]
+        rows = [[rng.randint(0, 4, size=len(r)).tolist() for r in rt] for rt in roads]
+        S = 4
+        buf = np.zeros((T, E, max(1, eng.n_entry), S), np.uint8)
+        for t in range(T):
+            for k in range(E):
+                pr = spawn_rows(eng, roads[t][k], rows[t][k])[0]
+                buf[t, k, :, :pr.shape[-1]] = pr
+        eng.set_actions(acts, per_tick=True)
+        eng.set_spawns(counts=np.stack([counts(eng, r) for r in roads]), per_tick=True, rows=buf)
+        eng.step(T)
+        ran += 2 * (T // 2)
+        for t in range(T):
+            orc.step(acts[t], roads[t], spawn_arch=rows[t], archetypes=tab10)
+        assert_cars_equal(eng, orc, tab10, "C=%d trial %d (%d ticks)" % (C, trial, T))
+        if validate:
+            nt = eng.n_trips.cpu().numpy()
+            assert np.array_equal(nt, orc.n_trips)
+            for k in range(E):
+                kk = min(int(nt[k]), eng.trip_cap)
+                assert np.array_equal(eng.trip_times[k, :kk].cpu().numpy(), orc.trip_times[k, :kk])
+    assert eng.pair_ticks() == ran and eng.step_kernel() == "k_move_tt"
+    assert eng.tail_ticks() == (ran if tail == "2" else 0) and (eng.split_ticks() > 0) == (split == "2")
+
+
+@pytest.mark.parametrize("remi", [False, True])
+def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
+    """tfx_agent_step with heterogeneous cars on a handle whose tfx_step calls run as pairs: the agent step itself goes one
+    tick at a time (k_risk's movement bound is for one archetype) but through the one-tick form of the pass, which reads
+    the columns a pair left behind; plain step() calls in between leave such columns.  Equal, bit for bit incl. every
+    car's row, to a handle that never uses the pairs (k_move_t<HET> + k_advance), through decisions that overflow."""
+    from test_gpu_fused import engine_with
+    from test_gpu_parity import random_state
+    tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
+                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
+    m, n, L, C, E = 3, 3, 120.0, 14, 9
+    kw = dict(planes=3, m=m, n=n, length=L, capacity=C, archetypes=tab8)
+    a = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": "2", "TFX_SPLIT": "2"}, E, **kw)
+    c = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "0"}, E, **kw)
+    rng = np.random.RandomState(777 + int(remi))
+    froze = 0
+    for trial, T in enumerate([3, 10, 4, 6]):
+        x, v, w, leading, lastcar = random_state(rng, E, a.R, C, L, crowd=rng.choice([0.5, 0.9]),
+                                                 beyond=rng.choice([0.0, 0.05, 0.4]), sorted_x=bool(trial % 2))
+        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        phase = rng.randint(2, size=(E, a.I)).astype(np.int32)
+        act = rng.randint(2, size=(E, a.I)).astype(np.int32)
+        period = int(rng.choice([1, 2, 5]))
+        for eng in (a, c):
+            eng.reset(phase)
+            eng.load_state(x, v, leading, lastcar, w=w, arch=arch)
+            eng.set_tick(40)
+            eng.set_spawns(period=period)
+            eng.set_actions(act)
+        for step in range(3):
+            ra = [t.clone() for t in a.agent_step(T, remi=remi)]
+            rc = [t.clone() for t in c.agent_step(T, remi=remi)]
+            for u, w_ in zip(ra, rc):
+                assert torch.equal(u, w_), (trial, step)
+            froze += int(ra[2].sum())
+            a.step(3)                 # a pair and a single tick: leaves columns that start a row or two down
+            c.step(3)
+            for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst", "done"):
+                assert torch.equal(getattr(a, name), getattr(c, name)), (name, trial, step)
+            ld, lc = a.leading.cpu().numpy(), a.lastcar.cpu().numpy()
+            pa, pb = a.planes_numpy(), c.planes_numpy()
+            aa, ab = a.arch.cpu().numpy(), c.arch.cpu().numpy()
+            for k in range(E):
+                live = live_mask(ld[k], lc[k], C)
+                for u, w_ in zip(pa, pb):
+                    assert same_bits(u[k][live], w_[k][live]), (trial, step, k)
+                assert np.array_equal(aa[k][live], ab[k][live]), (trial, step, k)
+    assert a.pair_ticks() > 0 and c.pair_ticks() == 0 and froze > 0
+
+
 def test_unsupported_archetype_tables_are_refused():
     with pytest.raises(TfxError):          # a non-integer exponent has no bit-exact power
         TfxEngine(2, 2, 100.0, 10, planes=3, archetypes=[[11.11, 4, 3, 2.5, 13.89, 6, 2, 1]])

@@ -26,7 +26,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
-  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
+  const bool split = !res_usable(h, n_ticks) && !h->poisson && !h->d.het && split_usable(h, n_ticks);
   if (split) {
     if (int rc = ensure_split(h, st)) return rc;
   }

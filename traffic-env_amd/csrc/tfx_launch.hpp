@@ -326,13 +326,14 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
 }
 
 // Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of two ticks or more on the transposed
-// layout whose launches fill the chip, identical cars (validate mode: the W forms carry the spawn-tick plane).  A handle
+// layout whose launches fill the chip (validate mode: the W forms carry the spawn-tick plane; heterogeneous cars: the
+// HET forms; agent steps of heterogeneous cars use the one-tick form only - k_risk's bound is for one archetype).  A handle
 // that can use them (pairs_usable(h)) runs ALL its single ticks through k_move_tt<false>: the one-tick form that
 // reads past the rows a pair may have left empty at the top of a column.
 bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   const Dev &d = h->d;
   // (a handle whose envs fit k_res never mixes the two: k_res loads its cars from row 0)
-  if (!h->pairs || d.layout != 1 || d.het || n_ticks < 2 || h->move_variant != 0 || h->res_epb > 0) return false;
+  if (!h->pairs || d.layout != 1 || n_ticks < 2 || h->move_variant != 0 || h->res_epb > 0) return false;
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
@@ -366,8 +367,9 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   int &resident = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
   if (resident == 0) {
     int per_cu = 0;
-    const auto occ = h->d.w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT, true>, 256, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT, false>, 256, 0);
+    const auto occ = h->d.het ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT, true, true>, 256, 0)
+                     : h->d.w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT, true>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_move_tt<TWO, AGENT, false>, 256, 0);
     if (occ != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 6) per_cu = 6;
     resident = h->n_cu * per_cu;
@@ -382,7 +384,8 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   if (grid < 1) grid = 1;
   const bool stagger = TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
-  if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
+  if (h->d.het) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true, true>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
+  else if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
   else hipLaunchKernelGGL((k_move_tt<TWO, AGENT, false>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
   HIPCHK(hipGetLastError());
   if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));
@@ -413,6 +416,8 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   s.rec = d.rec + L * R;
   s.rec2 = d.rec2 + L * R;
   s.tailx = d.tailx + L * R;
+  if (d.taila) s.taila = d.taila + L * R;
+  if (d.spawn_arch) s.spawn_arch = d.spawn_arch + L * (size_t)d.n_entry * (size_t)d.spawn_arch_S;
   s.leadx = d.leadx + L * R;
   s.outb = d.outb + L * out_pairs;
   if (d.outw) s.outw = d.outw + L * out_pairs;
@@ -434,7 +439,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
 // agent steps; tfx_step generates them up front), and not below one env per CU (a handful of big envs - cfg4 - has
 // too few workgroups to offer).  (The greedy controller decides inside the advance.)
 bool tail_usable(tfx_handle h) {
-  if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1 || h->d.het) return false;
+  if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1) return false;
   return h->tail == 2 || h->d.E >= h->n_cu;
 }
 
@@ -462,8 +467,12 @@ int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false) {
   }
   if (h->size_only) return TFX_OK;
   const dim3 g(h->grid_tail), b(256);
-  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0);
+  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
   switch (sel) {
+    case 12: hipLaunchKernelGGL((k_tail<false, false, true, true>), g, b, 0, st, h->d, tidx); break;
+    case 13: hipLaunchKernelGGL((k_tail<true, false, true, true>), g, b, 0, st, h->d, tidx); break;
+    case 14: hipLaunchKernelGGL((k_tail<false, true, true, true>), g, b, 0, st, h->d, tidx); break;
+    case 15: hipLaunchKernelGGL((k_tail<true, true, true, true>), g, b, 0, st, h->d, tidx); break;
     case 0: hipLaunchKernelGGL((k_tail<false, false, false>), g, b, 0, st, h->d, tidx); break;
     case 1: hipLaunchKernelGGL((k_tail<true, false, false>), g, b, 0, st, h->d, tidx); break;
     case 2: hipLaunchKernelGGL((k_tail<false, true, false>), g, b, 0, st, h->d, tidx); break;
@@ -479,7 +488,8 @@ int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false) {
 
 template <bool AGENT>
 int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
-  if (h->d.w) hipLaunchKernelGGL((k_edge<AGENT, true>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
+  if (h->d.het) hipLaunchKernelGGL((k_edge<AGENT, true, true>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
+  else if (h->d.w) hipLaunchKernelGGL((k_edge<AGENT, true>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   else hipLaunchKernelGGL((k_edge<AGENT, false>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;

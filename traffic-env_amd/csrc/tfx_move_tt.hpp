@@ -64,9 +64,18 @@ namespace tfx {
 #define TT_ATTR(W) __attribute__((amdgpu_waves_per_eu((W) ? TT_WAVES_W : TT_WAVES, (W) ? TT_WAVES_W : TT_WAVES)))
 // W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157): a car's side word
 // is stored wherever its (x, v) is
-template <bool TWO, bool AGENT = false, bool W = false>
+// HET (implies W): heterogeneous cars, as in k_move_t - the side word is 8 * spawn tick + the car's row of the archetype
+// table (LDS copy); a car's own row gives its IDM parameters in BOTH of its ticks, its leader's row the length the gap
+// subtracts (the walk carries the lengths of cars k-1 and k-2 along with their new states)
+template <bool TWO, bool AGENT = false, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
+  static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
   constexpr int P = TT_P;
+  __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
+  if (HET) {
+    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA - ((AGENT && only_risky == 2) ? 1 : 0);
@@ -114,6 +123,8 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
     float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
     float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
     float y1w = 0.0f;                                      // side word of car k-1
+    float y1l = 0.0f, y2l = 0.0f;                          // HET: lengths of cars k-1 and k-2
+    int last_a = 0;                                        // HET: table row of the last car processed (the road's tail)
     int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
     bool open = true, far = false;
     bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
@@ -139,9 +150,18 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
       float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
       // (one wave-wide test per row.  Round 3 measured the alternatives on this kernel: the speeds read from memory
       // tested once per group of P rows, 0.772 ms per pass against 0.764; no test at all - results wrong - 0.734)
-      const bool bad = (!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v));
-      const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
-      if (d.fastdiv && !off_domain) {
+      const bool bad = !HET && ((!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v)));
+      const bool off_domain = !HET && __builtin_amdgcn_ballot_w64(bad) != 0ull;
+      float my_l = d.car_l;
+      if (HET) {
+        if (!LAST) {
+          last_a = side_arch(sw);
+          const float *me = s_arch + last_a * ARCH_W;
+          idm_step_het(d, me, x, v, xprev, vprev, llv, xn, vn);
+          my_l = me[AR_L];
+        }
+        if (TWO) idm_step_het(d, s_arch + side_arch(y1w) * ARCH_W, y1x, y1v, y2x, y2v, y2l, zx, zv);
+      } else if (d.fastdiv && !off_domain) {
         if (!LAST) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
         if (TWO) idm_step_fast(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
       } else {
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
       if (LAST) return;
       xprev = x;
       vprev = v;
-      llv = d.car_l;
+      llv = my_l;
       const bool was_open = open;
       const bool pop = open && (xn > d.length);  // the while loop of :123
       open = pop;
@@ -195,6 +215,10 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
       y1x = xn;
       y1v = vn;
       if (W) y1w = sw;
+      if (HET) {
+        y2l = y1l;
+        y1l = my_l;
+      }
     };
 
     // ---- cars in memory: rows 0 .. kmax-1 of the live part, P rows in flight --------------------
@@ -230,8 +254,31 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
         smax = o > smax ? o : smax;
       }
       smax = __builtin_amdgcn_readfirstlane(smax);
-      for (int s = 0; s < smax; ++s)
-        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick, std::false_type{});
+      if (HET) {
+        // add_car :97-114 car by car: each queues behind the road's tail at the moment it is created - the tail's
+        // OWN length and minimum gap - and brings the row add_new_cars drew for it (:164); as in k_move_t
+        int lcq = ring_adv(p.ld, n_old, C);
+        float tx = d.tailx[id];
+        int ta = d.taila[id];
+        const int ej = d.entry_idx[e];
+        const uint8_t *rows = (d.spawn_arch && d.spawn_mode == TFX_SPAWN_COUNTS && ej >= 0)
+                                  ? d.spawn_arch + (size_t)tidx * d.spawn_arch_stride +
+                                        ((size_t)env * d.n_entry + ej) * d.spawn_arch_S
+                                  : nullptr;
+        for (int s = 0; s < smax; ++s)
+          if (s < n_sp) {
+            const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
+            const float start = (lcq != p.ld) ? (tx - s_arch[ta * ARCH_W + AR_L]) - s_arch[ta * ARCH_W + AR_S0] : INFINITY;
+            const float xs = (start < 0.0f) ? start : 0.0f;
+            step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack((float)tick, row), std::false_type{});
+            lcq = wrap1(lcq + 1, C);
+            tx = xs;
+            ta = row;
+          }
+      } else {
+        for (int s = 0; s < smax; ++s)
+          if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick, std::false_type{});
+      }
     }
     // ---- the road's last car through tick t+1 ----------------------------------------------------
     if (TWO && two && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
@@ -252,7 +299,8 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
         if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
       }
       if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
-      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
+                            n_tot | (HET ? last_a << 16 : 0));
       if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
       if (far || kpop > KP) d.env_flag[env] = tick + 1;
       if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
@@ -313,8 +361,11 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
 // The second tick of a pair for the cars k_move_tt<true> could not take through it (see the head of this
 // file), for the 64 roads of one tile: lane = road.  Runs after the advance of the first tick; same tile / lane
 // ownership as the pass, a few cars per road.  Returns the lane's vehicle-updates.
-template <bool AGENT, bool W = false>
-__device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx) {
+// HET: heterogeneous cars - `arch` is the caller's LDS copy of the archetype table; a deferred car's row comes from its
+// side word (or from the spawner's draw), its leader's length travels along with the leader's old state
+template <bool AGENT, bool W = false, bool HET = false>
+__device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx,
+                                         const float *arch = nullptr) {
   const int C = d.C;
   // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
   // one-tick launch of their own)
@@ -339,21 +390,31 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   const int kq = C - 1 - p.ld;
   float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
   float tail_x = 0.0f;
-  // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll); fresh: spawned this tick
-  auto car = [&](int i, float x, float v, bool fresh) {
+  int last_a = HET ? rec_taila(rc.w) : 0;  // HET: table row of the road's last car so far
+  // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll); fresh: spawned this tick (side word sw)
+  auto car = [&](int i, float x, float v, bool fresh, float sw = 0.0f) {
     float zx, zv;
-    idm_step(d, x, v, lx, lv, ll, zx, zv);
+    if (HET) {
+      if (!fresh) sw = wcol[(size_t)i * 64];
+      last_a = side_arch(sw);
+      const float *me = arch + last_a * ARCH_W;
+      idm_step_het(d, me, x, v, lx, lv, ll, zx, zv);
+      ll = me[AR_L];
+    } else {
+      if (W && fresh) sw = (float)tick;
+      idm_step(d, x, v, lx, lv, ll, zx, zv);
+      ll = d.car_l;
+    }
     lx = x;
     lv = v;
-    ll = d.car_l;
     const bool pop = open && (zx > d.length);
     open = pop;
     if (pop && kpop < KP) {
       ocol[(size_t)kpop * 64] = make_float2(zx, zv);
-      if (W) owcol[(size_t)kpop * 64] = fresh ? (float)tick : wcol[(size_t)i * 64];
+      if (W) owcol[(size_t)kpop * 64] = fresh ? sw : wcol[(size_t)i * 64];
     } else {  // (a popped car beyond the outbox stays in its row: uncompacted)
       col[(size_t)i * 64] = make_float2(zx, zv);
-      if (W && fresh) wcol[(size_t)i * 64] = (float)tick;
+      if (W && fresh) wcol[(size_t)i * 64] = sw;
     }
     if (pop) far = far || ((zx - d.length) > d.length);
     kpop += pop ? 1 : 0;
@@ -383,13 +444,39 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
       lx = __int_as_float(rc.z);
       lv = __int_as_float(r2.x);
       tail_x = __int_as_float(r2.w);
+      if (HET) {
+        last_a = rec_taila(rc.w);
+        ll = arch[last_a * ARCH_W + AR_L];
+      }
     }
   }
   for (int i = m0; i < n_old; ++i) {  // handed over by the first tick's advance
     const float2 c = col[(size_t)i * 64];
     car(i, c.x, c.y, false);
   }
-  for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v, true);  // spawned this tick
+  if (HET) {  // spawned this tick, car by car behind the tail's own length and gap (as in the pass)
+    if (n_tot > n_old) {
+      int lcq = ring_adv(p.ld, n_old, C);
+      float tx = d.tailx[id];
+      int ta = d.taila[id];
+      const int ej = d.entry_idx[e];
+      const uint8_t *rows = (d.spawn_arch && d.spawn_mode == TFX_SPAWN_COUNTS && ej >= 0)
+                                ? d.spawn_arch + (size_t)tidx * d.spawn_arch_stride +
+                                      ((size_t)env * d.n_entry + ej) * d.spawn_arch_S
+                                : nullptr;
+      for (int s = 0; s < n_tot - n_old; ++s) {
+        const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
+        const float start = (lcq != p.ld) ? (tx - arch[ta * ARCH_W + AR_L]) - arch[ta * ARCH_W + AR_S0] : INFINITY;
+        const float xs = (start < 0.0f) ? start : 0.0f;
+        car(n_old + s, xs, arch[row * ARCH_W + AR_V], true, side_pack((float)tick, row));
+        lcq = wrap1(lcq + 1, C);
+        tx = xs;
+        ta = row;
+      }
+    }
+  } else {
+    for (int s = 0; s < n_tot - n_old; ++s) car(n_old + s, spawned_x(d, p.xs0, s), d.car_v, true);  // spawned this tick
+  }
 
   const bool unc = kpop > KP;
   if (e < d.r) {
@@ -400,14 +487,19 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
   }
   d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
-                        __float_as_int(tail_x), n_tot);
+                        __float_as_int(tail_x), n_tot | (HET ? last_a << 16 : 0));
   if (far || unc) d.env_flag[env] = tick + 1;
   d.leadx[id] = p.xL;
   return n_tot;
 }
 
-template <bool AGENT, bool W = false>
+template <bool AGENT, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
+  __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
+  if (HET) {
+    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
@@ -417,7 +509,7 @@ __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
 
   unsigned long long my_updates = 0;
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw)
-    my_updates += (unsigned long long)edge_tile<AGENT, W>(d, tile, (int)(tile / d.G), lane, tick, tick_sp, tidx);
+    my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(d, tile, (int)(tile / d.G), lane, tick, tick_sp, tidx, s_arch);
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if (lane == 0 && my_updates) veh_add(d.veh, my_updates);

@@ -28,8 +28,16 @@ namespace tfx {
 // the advance of tick t here and their whole second tick from the two restricted launches that follow
 // (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).
 // W: validate mode - the cars' side words travel along (edge_tile)
-template <bool GREEDY = false, bool AGENT = false, bool W = false>
+// HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
+// from an LDS copy of the table
+template <bool GREEDY = false, bool AGENT = false, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
+  static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
+  __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
+  if (HET) {
+    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwv = blockDim.x >> 6;
@@ -39,13 +47,13 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY, W>(d, env, s, tick, tidx);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(d, env, s, tick, tidx);
     if (AGENT && d.env_risk[env] == tick + 1) continue;  // (workgroup-uniform; nobody waits at a barrier for it)
     __syncthreads();
     for (int g = wv; g < d.G; g += nwv)
-      my_updates += (unsigned long long)edge_tile<AGENT, W>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1);
+      my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch);
     __syncthreads();
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, false, GREEDY, W>(d, env, s, tick + 1, tidx + 1);
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(d, env, s, tick + 1, tidx + 1);
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);

@@ -1,6 +1,7 @@
 """Throughput of the heterogeneous-car path (archetype table, tfx_config.n_archetypes) at the headline shape: 4096 envs of
 16x16 x 64-car roads, the benchmark's prefill with every car given one of three table rows, periodic arrivals (row 0),
-fixed-cycle lights.  One kernel path (k_move_t<HET> + k_advance, tick by tick, 24 B per car and tick)."""
+fixed-cycle lights.  The HET forms of the two-tick pass and k_tail (TFX_PAIRS=0: k_move_t<HET> + k_advance, tick by
+tick); 24 B per car and pass."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "traffic-env_amd")]

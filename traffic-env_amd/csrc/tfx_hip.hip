@@ -7,8 +7,9 @@
 //   * otherwise per-tick kernels, from two ticks on as PAIRS:
 //       k_move_tt (tfx_move_tt.hpp)   the cars through two ticks per trip through HBM
 //       k_tail (tfx_tail.hpp)         advance of tick t, the deferred cars' tick t+1, advance of t+1: a workgroup per env
-//     with the env range in two halves on two streams (tfx_sequence.hpp; validate mode: the W forms of both kernels);
-//     small launches, heterogeneous cars and the ring layout: k_move_t / k_move_ts / k_move_dma / k_move<WPR> + k_advance.
+//     with the env range in two halves on two streams (tfx_sequence.hpp; validate mode: the W forms of both kernels,
+//     heterogeneous cars: the HET forms); small launches and the ring layout: k_move_t / k_move_ts / k_move_dma /
+//     k_move<WPR> + k_advance.
 // This file is the C ABI itself; the handle is in tfx_handle.hpp, kernel choice and launch geometry in tfx_launch.hpp,
 // the launch sequences of tfx_step / tfx_agent_step in tfx_sequence.hpp, the cold kernels in tfx_misc.hpp.
 #include <cmath>

@@ -26,8 +26,9 @@ def step_path(request, monkeypatch):
     yield request.param
 
 
-def emulate_agent_step(orcs, tick0, action, entry, n_ticks, remi, period):
-    """Repeater._step + Remi._step per env on single-env oracles; returns (aobs, areward, adone)."""
+def emulate_agent_step(orcs, tick0, action, entry, n_ticks, remi, period, archetypes=None):
+    """Repeater._step + Remi._step per env on single-env oracles; returns (aobs, areward, adone).
+    archetypes: the reference-shaped table of a run with heterogeneous cars (arrivals take row 0)."""
     E = len(orcs)
     r, I = orcs[0].r, orcs[0].I
     aobs = np.zeros((E, 2 * r + I), np.float32)
@@ -40,7 +41,7 @@ def emulate_agent_step(orcs, tick0, action, entry, n_ticks, remi, period):
         for t in range(n_ticks):
             tick = tick0 + t
             orc.steps[:] = tick                        # batched envs share one clock on the device
-            obs, rew, d = orc.step(action[k], [wl.spawn_roads_for_tick(entry, tick, period=period)])
+            obs, rew, d = orc.step(action[k], [wl.spawn_roads_for_tick(entry, tick, period=period)], archetypes=archetypes)
             obs, rew, done = obs[0], rew[0], bool(d[0])
             total_obs[:r] += obs[:r]
             total_obs[r:2 * r] = obs[r:2 * r]

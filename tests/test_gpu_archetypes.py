@@ -226,10 +226,10 @@ def test_mixed_rows_in_two_tick_pairs_vs_oracle(C, validate, tail, split):
 
 @pytest.mark.parametrize("remi", [False, True])
 def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
-    """tfx_agent_step with heterogeneous cars on a handle whose tfx_step calls run as pairs: the agent step itself goes one
-    tick at a time (k_risk's movement bound is for one archetype) but through the one-tick form of the pass, which reads
-    the columns a pair left behind; plain step() calls in between leave such columns.  Equal, bit for bit incl. every
-    car's row, to a handle that never uses the pairs (k_move_t<HET> + k_advance), through decisions that overflow."""
+    """tfx_agent_step with heterogeneous cars in two-tick pairs (k_risk bounds a car's movement with the table's LARGEST
+    acceleration), plain step() calls in between (they leave columns that start a row or two down).  Equal, bit for bit
+    incl. every car's row, to a handle that never uses the pairs (k_move_t<HET> + k_advance), through decisions that
+    overflow."""
     from test_gpu_fused import engine_with
     from test_gpu_parity import random_state
     tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
@@ -254,8 +254,10 @@ def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
             eng.set_spawns(period=period)
             eng.set_actions(act)
         for step in range(3):
+            p0 = a.pair_ticks()
             ra = [t.clone() for t in a.agent_step(T, remi=remi)]
             rc = [t.clone() for t in c.agent_step(T, remi=remi)]
+            assert a.pair_ticks() == p0 + 2 * (T // 2)        # the decision itself ran in pairs
             for u, w_ in zip(ra, rc):
                 assert torch.equal(u, w_), (trial, step)
             froze += int(ra[2].sum())

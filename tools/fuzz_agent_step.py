@@ -9,6 +9,7 @@ import numpy as np, torch
 from gym_traffic.core import TfxEngine
 from oracle.oracle import OracleEnv, live_mask
 from test_gpu_agent_step import emulate_agent_step
+from test_gpu_parity import random_state
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 t0, n, early = time.time(), 0, 0
@@ -26,19 +27,38 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2])))         # (plain step() calls between decisions: k_tail, split)
     os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))
     val = bool(rng.randint(3) == 0)                               # validate mode: spawn ticks travel, trip times are logged
-    eng = TfxEngine(m, nn, L, C, n_envs=E, planes=3 if (val or layout != "transposed") else 2, layout=layout, validate=val)
+    # heterogeneous cars (one case in four on the transposed layout): a random table, the run starts from a random
+    # ring state of mixed rows (arrivals are of row 0)
+    het = layout == "transposed" and rng.randint(4) == 0
+    tab8 = tab10 = None
+    if het:
+        na = int(rng.randint(1, 5))
+        tab8 = np.stack([np.array([rng.uniform(5, 14), rng.choice([3.0, 4.0, 7.5, 12.0]), rng.uniform(0.8, 4), float(rng.randint(1, 9)),
+                                   rng.uniform(8, 18), rng.uniform(2, 8), rng.uniform(1, 3), rng.uniform(0.5, 3)], np.float32) for _ in range(na)])
+        if na == 1 and tab8[0, 3] == 4.0: tab8[0, 3] = 2.0
+        tab10 = np.zeros((na, 10), np.float32); tab10[:, [1, 2, 3, 4, 5, 6, 7, 8]] = tab8
+    eng = TfxEngine(m, nn, L, C, n_envs=E, planes=3 if (val or het or layout != "transposed") else 2, layout=layout, validate=val,
+                    archetypes=tab8)
     orcs = [OracleEnv(m, nn, L, C, eng.dest, eng.phases, eng.nexts, validate=val) for _ in range(E)]
     ph = rng.randint(2, size=(E, eng.I)).astype(np.int32)
     eng.reset(ph)
     for k, o in enumerate(orcs):
         o.reset(ph[k])
+    if het:
+        x0, v0, w0, ld0, lc0 = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.2, 0.6]), beyond=rng.choice([0.0, 0.1]), sorted_x=True)
+        arch0 = rng.randint(0, len(tab8), size=x0.shape).astype(np.uint8)
+        eng.load_state(x0, v0, ld0, lc0, w=w0, arch=arch0)
+        for k, o in enumerate(orcs):
+            o.load_planes(0, x0[k], v0[k], w0[k], ld0[k], lc0[k], arch=arch0[k], archetypes=tab10)
+        eng.set_tick(60)
+        for o in orcs: o.steps[:] = 60
     eng.set_spawns(period=period)
     for step in range(int(rng.choice([4, 10, 16]))):
         act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
         eng.set_actions(act)
         tick0 = eng.tick
         aobs, arew, adone = eng.agent_step(T, remi=remi)
-        eobs, erew, edone = emulate_agent_step(orcs, tick0, act, eng.entrypoints, T, remi, period)
+        eobs, erew, edone = emulate_agent_step(orcs, tick0, act, eng.entrypoints, T, remi, period, archetypes=tab10)
         assert np.array_equal(adone.cpu().numpy(), edone), (n, step, "done")
         assert np.array_equal(aobs.cpu().numpy(), eobs), (n, step, "obs")
         assert np.array_equal(arew.cpu().numpy(), erew), (n, step, "reward")
@@ -50,6 +70,11 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
             live = live_mask(ld[k], lc[k], C)
             assert np.array_equal(xv[k][live][:, 0].view(np.int32), o.x[0][live].view(np.int32)), (n, step, k)
             assert np.array_equal(xv[k][live][:, 1].view(np.int32), o.v[0][live].view(np.int32)), (n, step, k)
+        if het:
+            ar = eng.arch.cpu().numpy()
+            for k, o in enumerate(orcs):
+                lv = live_mask(ld[k], lc[k], C)
+                assert np.array_equal(ar[k][lv], o.arch_plane(0, tab10)[lv]), (n, step, k, "rows")
         if val:
             w = eng.w.cpu().numpy()
             nt = eng.n_trips.cpu().numpy()

@@ -26,6 +26,7 @@ struct Dev {
   int agent_mode, accum_rewards;
   const int *agent_first;  // tick at which the current agent step began
   float length, rate, car_v, car_l, car_a, car_v0, car_b, car_T, car_s0;
+  float risk_a;                  // the largest acceleration any car can have (k_risk's movement bound): car_a, or the table's maximum
   float two_sab, eps, thresh, near_end, ovf_pen;
   float r_two_sab, r_v0;  // correctly rounded reciprocals of the two constant divisors
   int fastdiv;            // the reciprocal form of those divisions was verified exact (div_selftest)

@@ -27,7 +27,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
-  const bool split = !res_usable(h, n_ticks) && !h->poisson && !h->d.het && split_usable(h, n_ticks);
+  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
   if (split) {
     if (int rc = ensure_split(h, st)) return rc;
   }
@@ -159,6 +159,9 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.rate = cfg->rate;
   d.car_v = cfg->car_v; d.car_l = cfg->car_l; d.car_a = cfg->car_a; d.car_v0 = cfg->car_v0;
   d.car_b = cfg->car_b; d.car_T = cfg->car_T; d.car_s0 = cfg->car_s0;
+  d.risk_a = cfg->car_a;
+  if (het)
+    for (int a = 0; a < n_arch; ++a) d.risk_a = a == 0 ? arch_rows[0][2] : fmaxf(d.risk_a, arch_rows[a][2]);
   d.two_sab = 2.0f * sqrtf(cfg->car_a * cfg->car_b);  // 2 * np.sqrt(a*b) (traffic_env.py:54)
   d.eps = cfg->eps;
   d.r_two_sab = 1.0f / d.two_sab;

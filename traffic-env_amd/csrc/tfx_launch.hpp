@@ -327,7 +327,7 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
 
 // Two ticks per pass over the cars (tfx_move_tt.hpp): for calls of two ticks or more on the transposed
 // layout whose launches fill the chip (validate mode: the W forms carry the spawn-tick plane; heterogeneous cars: the
-// HET forms; agent steps of heterogeneous cars use the one-tick form only - k_risk's bound is for one archetype).  A handle
+// HET forms).  A handle
 // that can use them (pairs_usable(h)) runs ALL its single ticks through k_move_tt<false>: the one-tick form that
 // reads past the rows a pair may have left empty at the top of a column.
 bool pairs_usable(tfx_handle h, int n_ticks = 2) {

@@ -323,8 +323,9 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-  // the farthest a car can move in a tick beyond rate * v: the IDM acceleration is at most a (:56-57)
-  const float half_ar2 = (0.5f * (d.car_a * d.rate)) * d.rate;
+  // the farthest a car can move in a tick beyond rate * v: the IDM acceleration is at most a (:56-57: a * (1 - q^delta - u^2)
+  // with q >= 0), for heterogeneous cars at most the table's largest a
+  const float half_ar2 = (0.5f * (d.risk_a * d.rate)) * d.rate;
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);
     if (env_frozen(d, env, tick)) continue;

@@ -87,8 +87,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     if (tt) {
       // two-tick passes (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
       // tick at a time (k_risk)
-      // (heterogeneous cars: one tick at a time - k_risk bounds a car's movement with ONE archetype's acceleration)
-      for (; !d.het && t + 1 < n_ticks && rc == TFX_OK; t += 2) {
+      for (; t + 1 < n_ticks && rc == TFX_OK; t += 2) {
         rc = launch_inputs(h, st);
         if (rc == TFX_OK) rc = launch_risk(h, t, st);
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);

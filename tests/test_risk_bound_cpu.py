@@ -54,3 +54,39 @@ def test_no_car_moves_beyond_the_reach_k_risk_computes(rate, sorted_x):
             checked += int(live.sum())
             left += int((x1 > length).sum())
     assert checked > 5000 and left > 50
+
+
+@pytest.mark.parametrize("sorted_x", [True, False])
+def test_the_bound_with_the_largest_acceleration_of_a_table_of_archetypes(sorted_x):
+    """Heterogeneous cars: k_risk uses the table's LARGEST a (Dev.risk_a).  Every row's acceleration is
+    a_row * (1 - q^delta - u^2) <= a_row <= a_max for any integer exponent, so the same reach holds for mixed rows."""
+    rng = np.random.RandomState(77 + int(sorted_x))
+    m, n, C, length, E, rate = 3, 2, 20, 150.0, 6, 0.5
+    g = GridRoad(m, n, length)
+    orc = OracleEnv(m, n, length, C, g.dest, g.phases, g.nexts, n_envs=E, rate=rate)
+    tab10 = np.zeros((4, 10), np.float32)
+    tab10[:, 1:9] = [[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
+                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]]
+    r32 = np.float32(rate)
+    half_ar2 = (np.float32(0.5) * (np.float32(tab10[:, 3].max()) * r32)) * r32
+    checked = left = 0
+    for trial in range(10):
+        x, v, w, leading, lastcar = random_state(rng, E, orc.R, C, length, crowd=rng.choice([0.3, 0.9]),
+                                                 beyond=rng.choice([0.0, 0.1, 1.6]), sorted_x=sorted_x)
+        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        orc.reset(rng.randint(2, size=orc.I).astype(np.int32))
+        for k in range(E):
+            orc.load_planes(k, x[k], v[k], w[k], leading[k], lastcar[k], arch=arch[k], archetypes=tab10)
+        orc.obs[:, 2 * orc.r + orc.I:] = rng.randint(0, 12, size=(E, orc.I))
+        orc.move_cars()
+        for k in range(E):
+            live = live_mask(leading[k], lastcar[k], C)
+            x0, v0 = x[k][live].astype(np.float32), v[k][live].astype(np.float32)
+            with np.errstate(all="ignore"):
+                reach = x0 + np.maximum(r32 * v0 + half_ar2, np.float32(0.0))
+            x1 = orc.x[k][live]
+            ok = np.isnan(x1) | (x1 <= reach)
+            assert ok.all(), (trial, k, x0[~ok][:3], v0[~ok][:3], x1[~ok][:3], reach[~ok][:3])
+            checked += int(live.sum())
+            left += int((x1 > length).sum())
+    assert checked > 4000 and left > 40

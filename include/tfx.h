@@ -108,7 +108,7 @@ typedef struct tfx_config {
    * :164).  n_archetypes <= 1: the single archetype of the car_* fields above (the reference's default), and the
    * table is ignored.  n_archetypes in 2..TFX_MAX_ARCH, or one row whose delta is not 4: "heterogeneous cars" -
    * every car carries the row it was spawned from through handoffs; needs layout = 1 and planes = 3 (the per-car
-   * side word then holds 8 * spawn tick + row), runs on the tick-by-tick kernels, and takes the rows of spawned
+   * side word then holds 8 * spawn tick + row; the envs never run LDS-resident), and takes the rows of spawned
    * cars from tfx_set_spawn_archetypes.  delta must be an integer in 1..8: (v/v0)**delta is the binary64 product
    * chain of oracle/idm_oracle.c powi_cr rounded once (for 4: the same value as the single-archetype path).
    * Row layout: v (spawn speed), l, a, delta, v0, b, T, s0. */

@@ -349,14 +349,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            # RCCL prints a version banner on STDOUT when its communicator comes up: stdout carries the one JSON line and
-            # nothing else, so file descriptor 1 points at stderr until the communicator exists
-            with stdout_to_stderr():
+        # RCCL prints a version banner on STDOUT when its communicator comes up (gloo a line per rank): stdout carries
+        # the one JSON line and nothing else, so file descriptor 1 points at stderr until the communicator exists
+        with stdout_to_stderr():
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
                 dist.init_process_group("nccl", device_id=device)
-                dist.barrier()
+            dist.barrier()
 
     # With a process group the ticks run on a HIGH-priority stream (the handle's second stream is then a low-priority
     # one): HIP shares its hardware queues among the streams of one priority level, and RCCL's own streams and

@@ -49,7 +49,7 @@ struct tfx_handle_s {
   int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
   int grid_adv = 0;
-  int grid_tail = 0;
+  int grid_tail = 0, grid_tail_half = 0;  // k_tail: workgroups of 256 lanes / of 128 (the halves of a split call)
   int tail = 1;               // k_tail after a two-tick pass (tfx_tail.hpp): TFX_TAIL=0 never, 2 at any batch size
   // calls of pairs run as TWO halves of the env range, the second on a stream of the handle's own: the latency-bound
   // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)

@@ -454,19 +454,26 @@ bool split_usable(tfx_handle h, int n_ticks) {
   return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
 }
 
-// (256 lanes per workgroup and as many workgroups as fit, measured at cfg2 against 512 / 1024 lanes and 2 / 3
-// workgroups per CU: 0.088 ms per tick against 0.090-0.131 - the launch lives on wavefronts in flight)
+// Workgroup size (the kernel takes any multiple of 64).  Alone on the chip 256 lanes and as many workgroups as fit are
+// best (measured at cfg2 against 128 / 192 / 320 / 384 / 512 / 1024 lanes: 0.091 ms per tick against 0.096 / 0.113 /
+// 0.098 / 0.119 / 0.090-0.131 - the launch lives on wavefronts in flight).  As one half of a split call, next to the
+// other half's pass, SMALLER workgroups win: they fit the gaps the pass leaves (vehicle-updates per second of the whole
+// call, same box: 64 lanes 5.15-5.18e11, 128 lanes 5.24-5.32e11, 192 5.10e11, 256 5.03-5.09e11, 320 4.76e11, 384 4.72e11).
 int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false) {
   if (h->grid_tail == 0) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_tail<false, false>), 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 5 && h->greedy) per_cu = 5;
-    long g = (long)h->n_cu * per_cu;
-    if (g > h->d.E) g = h->d.E;
-    h->grid_tail = (int)(g < 1 ? 1 : g);
+    for (int half = 0; half < 2; ++half) {
+      const int threads = half ? 128 : 256;
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_tail<false, false>), threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (per_cu > (half ? 10 : 5) && h->greedy) per_cu = half ? 10 : 5;
+      long g = (long)h->n_cu * per_cu;
+      if (g > h->d.E) g = h->d.E;
+      (half ? h->grid_tail_half : h->grid_tail) = (int)(g < 1 ? 1 : g);
+    }
   }
   if (h->size_only) return TFX_OK;
-  const dim3 g(h->grid_tail), b(256);
+  const bool halves = h->split_half >= 0;
+  const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? 128 : 256);
   const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
   switch (sel) {
     case 12: hipLaunchKernelGGL((k_tail<false, false, true, true>), g, b, 0, st, h->d, tidx); break;

@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -106,19 +107,20 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
 
 
 def load_pmc_traffic(name, kernel, field="hbm_bytes_per_tick"):
-    """HBM bytes per tick of the kernel that moves the cars, from the committed rocprofv3 PMC summary
-    (profiles/pmc_<cfg>.json, tools/pmc_summary.py) - only if it was taken for this workload, this
-    kernel AND these kernel sources (the summary carries a hash of csrc/); otherwise null."""
+    """A figure of the kernel that moves the cars from the committed rocprofv3 PMC summary (profiles/pmc_<cfg>.json,
+    tools/pmc_summary.py) - only if it was taken for this workload, this kernel AND this kernel's machine code: the
+    summary carries the hash of the kernel's instructions in the library that was profiled (taken on the box by
+    tools/profile_round.sh, tools/kernel_hash.py); the library this process drives must have the same.  Otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_%s.json" % name)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from pmc_summary import csrc_hash
+        from kernel_hash import kernel_hashes
         with open(path) as f:
             d = json.load(f)
-        if d.get("kernel") != kernel or d.get("csrc_hash") != csrc_hash():
+        if d.get("kernel") != kernel or not d.get("kernel_hash") or d.get("kernel_hash") != kernel_hashes().get(kernel):
             return None
         return d.get(field)
-    except (OSError, ValueError, ImportError):
+    except (OSError, ValueError, ImportError, RuntimeError, subprocess.CalledProcessError):
         return None
 
 
@@ -127,7 +129,7 @@ VALU_PEAK_GINST = 1024 * 2.4 / 2.0   # wave64 vector instructions per ns the chi
 #                                      `v_fma_f32 (wave64) 2 cyc`) = 1228.8 G wave-instructions / s
 
 
-def roofline(a, c, eng, E, prof, prof_updates, gathering, dt, updates):
+def roofline(a, c, eng, E, prof, prof_updates, chunk, dt, updates):
     """The dominant kernel against the roofline that bounds it.
 
     HBM-bound kernels (the streaming move kernels): ALGORITHMIC bytes of one launch / its mean duration / 8 TB/s.
@@ -150,7 +152,9 @@ def roofline(a, c, eng, E, prof, prof_updates, gathering, dt, updates):
     kernel = eng.step_kernel()
     if 2 * (eng.pair_ticks()) >= K and kernel.startswith("k_move_tt"):
         kernel = "k_move_tt"
-    tpl = ((GATHER_EVERY if gathering else K) if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)
+    call = min(chunk, K)                                                # ticks per tfx_step call
+    tpl = (call if kernel in ("k_res", "k_env") else 2 if kernel == "k_move_tt" else 1)     # ticks per LAUNCH
+    passes = (tpl + 1) // 2 if kernel in ("k_env", "k_move_tt") else tpl     # trips of the cars through HBM per launch
     launch_ms = move_ms * tpl
     full = E == c["envs"]
     if kernel == "k_res":
@@ -164,31 +168,32 @@ def roofline(a, c, eng, E, prof, prof_updates, gathering, dt, updates):
                         "the bound is vector-instruction issue (count from the PMC pass x 2 cycles per wave64 "
                         "instruction / 1024 SIMDs / 2.4 GHz)"}
     road_ticks = E * eng.R
-    alg = 16.0 * live + tpl * 48.0 * road_ticks
+    alg = 16.0 * live * passes + tpl * 48.0 * road_ticks
     achieved = alg / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic = load_pmc_traffic(a.config, kernel, "k_move_hbm_bytes_per_launch") if full else None
+    per_tick = load_pmc_traffic(a.config, kernel, "hbm_bytes_per_tick") if full else None
+    traffic = per_tick * tpl if per_tick else None
     per_tick_model = tpl * (16.0 * live + 48.0 * road_ticks)
+    region_bytes = 16.0 * (updates / max(1, a.steps)) * passes + tpl * (48.0 * road_ticks + 32.0 * E * eng.I)
+    region_s = tpl * dt / max(1, a.steps)
     return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_frac": traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and launch_ms > 0 else None,
             "frac_of_measured_stream_peak": achieved / HBM_STREAM_GBS,
             "algorithmic_bytes_per_launch": alg, "launch_ms": launch_ms, "ticks_per_launch": tpl,
-            "ticks_timed": K, "rest_of_tick_ms": rest_ms,
+            "passes_per_launch": passes, "ticks_timed": K, "rest_of_tick_ms": rest_ms,
             "per_tick_model": {"bytes_per_launch": per_tick_model,
                                "rate_GBs": per_tick_model / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
                                "note": "SURVEY 8d's 16 B per vehicle-UPDATE x the updates of the launch: counts the "
-                                       "cars once per tick although a T-tick pass moves them once; not a fraction "
+                                       "cars once per tick although a two-tick pass moves them once; not a fraction "
                                        "of the HBM peak"},
-            # the whole timed region against the same peak, same byte model: per T ticks every live car once (16 B) and
-            # the per-road / per-intersection words once per tick, over the wall time of T ticks (the launches of the two
-            # env halves overlap there, and the per-road launches are in it)
-            "timed_region": {"GBs": (16.0 * (updates / max(1, a.steps)) + tpl * (48.0 * road_ticks + 32.0 * E * eng.I))
-                                    / (tpl * dt / max(1, a.steps)) / 1e9,
-                             "frac": (16.0 * (updates / max(1, a.steps)) + tpl * (48.0 * road_ticks + 32.0 * E * eng.I))
-                                     / (tpl * dt / max(1, a.steps)) / 1e9 / HBM_PEAK_GBS},
+            # the whole timed region against the same peak, same byte model: per pass every live car once (16 B), the
+            # per-road / per-intersection words once per tick, over the wall time of the region (median repeat)
+            "timed_region": {"GBs": region_bytes / region_s / 1e9, "frac": region_bytes / region_s / 1e9 / HBM_PEAK_GBS},
             "measured": "HIP events on the launch stream around every launch of the kernel, in a second pass over "
-                        "the same K ticks right after the timed region (no events inside the timed region; the env "
-                        "range is not split over two streams while a launch is timed)"}
+                        "the same K ticks right after the timed regions (no events inside a timed region; the env "
+                        "range is not split over two streams while a launch is timed).  k_env: one launch = all the "
+                        "ticks of a tfx_step call (the cars make (ticks + 1) // 2 trips through HBM, the per-road words "
+                        "stay in LDS and are charged at the model's 48 B per road and tick all the same)"}
 
 
 def numpy_baseline(name, budget_s=8.0):

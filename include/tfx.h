@@ -45,9 +45,9 @@
 extern "C" {
 #endif
 
-#define TFX_ABI_VERSION 10
+#define TFX_ABI_VERSION 11
 #define TFX_KP 2 /* popped cars carried per road per tick on the parallel path; more -> exact serial path */
-#define TFX_MAX_ARCH 8 /* rows of the archetype table (traffic_env.py:35-43 ships one) */
+#define TFX_MAX_ARCH 64 /* rows of the archetype table (traffic_env.py:35-43 ships one); a power of two */
 
 enum {
   TFX_OK = 0,
@@ -108,7 +108,7 @@ typedef struct tfx_config {
    * :164).  n_archetypes <= 1: the single archetype of the car_* fields above (the reference's default), and the
    * table is ignored.  n_archetypes in 2..TFX_MAX_ARCH, or one row whose delta is not 4: "heterogeneous cars" -
    * every car carries the row it was spawned from through handoffs; needs layout = 1 and planes = 3 (the per-car
-   * side word then holds 8 * spawn tick + row; the envs never run LDS-resident), and takes the rows of spawned
+   * side word then holds (spawn tick mod 2^24) << 6 | row as integer bits; the envs never run LDS-resident), and takes the rows of spawned
    * cars from tfx_set_spawn_archetypes.  delta must be an integer in 1..8: (v/v0)**delta is the binary64 product
    * chain of oracle/idm_oracle.c powi_cr rounded once (for 4: the same value as the single-archetype path).
    * Row layout: v (spawn speed), l, a, delta, v0, b, T, s0. */
@@ -166,6 +166,13 @@ int tfx_set_spawns(tfx_handle h, int32_t mode, const int32_t *dev, int32_t perio
  * P(gap <= k) * 2^32 for k = 0.. (the last entry must be 0xFFFFFFFF); gym_traffic/devrng.py builds it
  * and mirrors the stream on the host. */
 int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uint32_t *cdf, int32_t n_cdf);
+/* On-device form of the reference's `regular` generator (traffic_env.py:167-176): with cars_per_tick =
+ * cars_per_sec * rate, `burst` = ceil(cars_per_tick) cars in every tick i of the env's generator with
+ * i % every == 0, `every` = round(1 / cars_per_tick) (Python's round: half to even; every == 0 means every tick) -
+ * the caller passes the two integers; each car on a uniformly drawn entry road (rand.choice(entrypoints), :280) from the
+ * Philox stream keyed by (seed, global env id), car c using the same draw index as car c of tfx_set_poisson's stream.
+ * The per-tick car COUNTS are exactly the reference's; gym_traffic/devrng.py mirrors the road draws on the host. */
+int tfx_set_regular(tfx_handle h, int32_t every, int32_t burst, uint64_t seed);
 /* Heterogeneous cars only: the archetype row of every car the count buffer of tfx_set_spawns adds
  * (`archetypes[random.randint(archetypes.shape[0])]`, traffic_env.py:164): device uint8
  * [n_ticks or 1][E][n_entry][per_road], entry j of a road = its j-th car of the tick in creation order (cars
@@ -253,6 +260,14 @@ int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
  * second tick's inputs are produced on the device in between (tfx_set_poisson, TFX_ACTION_GREEDY).  TFX_TAIL=0
  * turns it off, TFX_TAIL=2 forces it at any batch size; results are bit-identical. */
 int tfx_tail_ticks(tfx_handle h, int64_t *ticks);
+/* Ticks of this handle that ran in k_env (csrc/tfx_env.hpp): ONE launch per tfx_step / tfx_agent_step call, a workgroup
+ * per env for all the ticks of the call - the cars streamed from HBM in two-tick passes, the env's ring words (leading,
+ * lastcar, the tails, the road records, the lights) resident in LDS from the first tick to the last.  Taken on its own
+ * for calls of two ticks or more on the transposed layout from two envs per compute unit on, when an env's words fit a
+ * workgroup's LDS (28 bytes per road: up to ~5 800 roads) and every tick's inputs exist before the call (everything
+ * but the Poisson stream inside agent steps); results are bit-identical to the per-tick kernels.  TFX_ENVK=0 turns it
+ * off, TFX_ENVK=2 forces it at any batch size. */
+int tfx_env_ticks(tfx_handle h, int64_t *ticks);
 /* Ticks of tfx_step calls that ran as two halves of the env range, the second half on a stream the handle owns
  * (forked from and joined to the caller's stream with events, so the call keeps its stream semantics): the
  * latency-bound per-road launch of one half then runs under the other half's pass over the cars.  Used for calls
@@ -262,6 +277,13 @@ int tfx_split_ticks(tfx_handle h, int64_t *ticks);
 /* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
  * "k_move_dma", ...), for the roofline report; "" before the first step */
 const char *tfx_step_kernel(tfx_handle h);
+
+/* Error-path testing: the n-th kernel launch a later tfx_step / tfx_agent_step / tfx_move_cars /
+ * tfx_advance_finished_cars call would make (counted from this call, over calls) is not made and that call returns
+ * TFX_EDEVICE instead.  The handle stays usable: its second stream is joined back, nothing a sequence changes in the
+ * handle while it enqueues stays changed; the envs' state is then somewhere inside the failed call (reset or reload
+ * it).  0 switches the injection off. */
+int tfx_debug_fail_after(tfx_handle h, int32_t n_launches);
 
 /* Host-side replay of the reference's seeded arrival generators for many envs (no GPU involved): one
  * stream per env holds a legacy numpy RandomState's MT19937 state (`RandomState.get_state()[1:3]`)

@@ -168,17 +168,37 @@ def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
                 assert np.array_equal(eng.trip_times[k, :nt[k]].cpu().numpy(), orc.trip_times[k, :nt[k]])
 
 
+FOUR_ROWS = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
+                      [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
+
+
 @pytest.mark.parametrize("tail,split", [("2", "0"), ("0", "0"), ("2", "2")])
 @pytest.mark.parametrize("C,validate", [(10, False), (34, True), (66, False)])
 def test_mixed_rows_in_two_tick_pairs_vs_oracle(C, validate, tail, split):
     """The same pathological states through multi-tick calls: the HET forms of the two-tick pass, of k_edge / k_tail and
     the two-stream split (forced at test size).  A car's own row drives BOTH of its ticks in the pass, its leader's row
     the gap; arrivals of mixed rows come from per-tick count and row buffers."""
+    run_pairs_case(C, validate, tail, split, FOUR_ROWS, 60)
+
+
+@pytest.mark.parametrize("tail,split", [("2", "2"), ("0", "0")])
+def test_rows_survive_a_long_clock_and_a_wide_table(tail, split):
+    """Round-3 advisor finding: the side word held 8 * tick + row as a FLOAT value, so from tick 2^21 on the row was
+    rounded away and new cars got wrong parameters.  It now holds (tick mod 2^24) << 6 | row as integer bits: 40 table
+    rows (the old limit was 8), the clock at 3 million ticks, validate mode - every car's row, spawn tick and trip time
+    still equal the oracle's, which carries all ten parameters per car."""
+    rng = np.random.RandomState(31)
+    tab8 = np.stack([rng.uniform(7, 13, 40), rng.uniform(3, 12, 40), rng.uniform(1, 4, 40), rng.randint(1, 9, 40),
+                     rng.uniform(9, 17, 40), rng.uniform(3, 7, 40), rng.uniform(1.2, 3, 40), rng.uniform(1, 3, 40)],
+                    axis=1).astype(np.float32)
+    run_pairs_case(34, True, tail, split, tab8, 3000000)
+
+
+def run_pairs_case(C, validate, tail, split, tab8, tick0):
     from test_gpu_fused import engine_with
     from test_gpu_parity import random_state
-    tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
-                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
-    tab10 = np.zeros((4, 10), np.float32)
+    n_rows = len(tab8)
+    tab10 = np.zeros((n_rows, 10), np.float32)
     tab10[:, ROWS] = tab8
     m, n, L, E = 3, 2, 150.0, 5
     eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": tail, "TFX_SPLIT": split}, E, planes=3,
@@ -189,18 +209,20 @@ def test_mixed_rows_in_two_tick_pairs_vs_oracle(C, validate, tail, split):
     for trial, T in enumerate([2, 5, 4, 7, 3, 6]):
         x, v, w, leading, lastcar = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.3, 0.8]),
                                                  beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=bool(trial % 2))
-        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        arch = rng.randint(0, n_rows, size=x.shape).astype(np.uint8)
+        if tick0 > 400:     # the cars on the roads were spawned in the last few hundred ticks
+            w = (tick0 - 400 + 8 * w).astype(np.float32)
         phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
         eng.reset(phase)
         orc.reset(phase)
         eng.load_state(x, v, leading, lastcar, w=w, arch=arch)
         for k in range(E):
             orc.load_planes(k, x[k], v[k], w[k], leading[k], lastcar[k], arch=arch[k], archetypes=tab10)
-        eng.set_tick(60)
-        orc.steps[:] = 60
+        eng.set_tick(tick0)
+        orc.steps[:] = tick0
         acts = rng.randint(2, size=(T, E, eng.I)).astype(np.int32)
         roads = [[rng.choice(eng.entrypoints, size=rng.randint(0, 4)).tolist() for _ in range(E)] for _ in range(T)]
-        rows = [[rng.randint(0, 4, size=len(r)).tolist() for r in rt] for rt in roads]
+        rows = [[rng.randint(0, n_rows, size=len(r)).tolist() for r in rt] for rt in roads]
         S = 4
         buf = np.zeros((T, E, max(1, eng.n_entry), S), np.uint8)
         for t in range(T):

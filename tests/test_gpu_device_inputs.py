@@ -183,3 +183,104 @@ def test_poisson_generated_up_front_in_chunks(step_path):
     assert np.array_equal(a.leading.cpu().numpy(), orc.leading) and np.array_equal(a.lastcar.cpu().numpy(), orc.lastcar)
     assert np.array_equal(a.obs.cpu().numpy(), orc.obs)
     assert int(a.cars_on_roads_flat().sum()) > 50
+
+
+def test_per_tick_actions_follow_the_call_across_poisson_chunks(step_path):
+    """A per-tick action buffer is indexed by the tick of the WHOLE call while the arrivals are drawn in chunks of the
+    rows the count buffer holds: 150 ticks in one call (three chunks) == fifteen calls of 10 ticks fed rows 10k..10k+9,
+    == the oracle under the host mirror of the stream (round-3 advisor finding: chunks restarted the action row at 0)."""
+    if step_path == "resident":
+        pytest.skip("the per-tick kernels' arrival stream (k_res draws inside its launch)")
+    E, m, n, L, cap, cpt, seed, T = 4, 3, 3, 140.0, 20, 0.9, 91, 150
+    rng = np.random.RandomState(5)
+    acts = np.repeat(rng.randint(2, size=(T // 5, E, m * n)), 5, axis=0).astype(np.int32)      # a new action every 5 ticks
+    a = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    b = TfxEngine(m, n, L, cap, n_envs=E, planes=2)
+    orc = OracleEnv(m, n, L, cap, a.dest, a.phases, a.nexts, n_envs=E)
+    ph = np.zeros((E, a.I), np.int32)
+    for e in (a, b):
+        e.reset(ph)
+        e.set_poisson(cpt, seed=seed)
+    orc.reset(ph)
+    a.set_actions(torch.as_tensor(acts).to(a.device), per_tick=True)
+    a.step(T)
+    for k in range(T // 10):
+        b.set_actions(torch.as_tensor(acts[10 * k:10 * k + 10]).to(b.device), per_tick=True)
+        b.step(10)
+    for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    mirror = PoissonMirror(cpt, seed, a.n_entry, range(E))
+    for t in range(T):
+        cnt = mirror.next_tick()
+        orc.step(acts[t], [[int(a.entrypoints[j]) for j in range(a.n_entry) for _ in range(cnt[q, j])] for q in range(E)])
+    assert np.array_equal(a.leading.cpu().numpy(), orc.leading) and np.array_equal(a.lastcar.cpu().numpy(), orc.lastcar)
+    assert np.array_equal(a.obs.cpu().numpy(), orc.obs)
+
+
+def golden_regular_counts(g):
+    """cars per tick of a reference-captured run under the `regular` generator, and its cars_per_tick"""
+    off = g["spawn_off"]
+    return np.diff(off).astype(np.int64), float(g["cars_per_sec"]) * g.sc["rate"]
+
+
+@pytest.mark.parametrize("name", ["g2x2_s0_reg_c20", "g2x2_s2_reg_c10"])
+def test_device_regular_generator_counts_and_roads(name, golden_cache, step_path):
+    """tfx_set_regular (the reference's `regular`, traffic_env.py:167-176, on the device): the cars made per tick are
+    EXACTLY the reference's captured schedule (ceil(cpt) every round(1 / cpt) ticks), each car's entry road is the host
+    mirror's draw bit for bit (gym_traffic/devrng.py RegularMirror), and the trajectory equals the oracle's under the
+    mirrored arrivals - tick by tick, in multi-tick calls and through fused decisions."""
+    from gym_traffic.devrng import RegularMirror
+    g = golden_cache(name)
+    sc = g.sc
+    per_tick, cpt = golden_regular_counts(g)
+    E, off, seed, T = 3, 5, 0xABCDEF12345, 60
+    eng = TfxEngine(sc["m"], sc["n"], sc["L"], sc["C"], n_envs=E, planes=2, rate=sc["rate"], env_id_offset=off)
+    orc = OracleEnv(sc["m"], sc["n"], sc["L"], sc["C"], eng.dest, eng.phases, eng.nexts, n_envs=E)
+    ph = np.zeros((E, eng.I), np.int32)
+    eng.reset(ph)
+    orc.reset(ph)
+    eng.set_regular(cpt, seed=seed)
+    eng.set_actions(cycle_period=7)
+    mirror = RegularMirror(cpt, seed, eng.n_entry, range(off, off + E))
+    t = 0
+    for k in (1, 4, 1, 7, 2, 10, 3, 1, 9, 6, 16):
+        eng.step(k)
+        for _ in range(k):
+            cnt = mirror.next_tick()
+            assert (cnt.sum(axis=1) == per_tick[t]).all(), t          # the reference's own count for this tick
+            act = (((t + (np.arange(off, off + E) % 7)) // 7) & 1).astype(np.int32)
+            orc.step(np.repeat(act[:, None], eng.I, axis=1),
+                     [[int(eng.entrypoints[j]) for j in range(eng.n_entry) for _ in range(cnt[q, j])] for q in range(E)])
+            t += 1
+        assert np.array_equal(eng.leading.cpu().numpy(), orc.leading), (k, t)
+        assert np.array_equal(eng.lastcar.cpu().numpy(), orc.lastcar), (k, t)
+        assert np.array_equal(eng.obs.cpu().numpy(), orc.obs), (k, t)
+    assert t == T and int(eng.cars_on_roads_flat().sum()) > 10
+    # sharding independence: global env `off + 1` alone
+    solo = TfxEngine(sc["m"], sc["n"], sc["L"], sc["C"], n_envs=1, planes=2, rate=sc["rate"], env_id_offset=off + 1)
+    solo.reset(ph[:1])
+    solo.set_regular(cpt, seed=seed)
+    solo.set_actions(cycle_period=7)
+    solo.step(T)
+    assert torch.equal(solo.leading[0], eng.leading[1]) and torch.equal(solo.obs[0], eng.obs[1])
+
+
+def test_vec_env_regular_device_arrivals():
+    """TrafficVecEnv(spawn='regular_device'): the batched surface over tfx_set_regular, fused decisions included."""
+    from gym_traffic.envs.vec_env import TrafficVecEnv
+    venv = TrafficVecEnv(6, 3, 3, 150.0, capacity=20, spawn='regular_device', local_cars_per_sec=0.2, seed=4)
+    ph = np.zeros((6, venv.engine.I), np.int32)
+    venv.reset(ph)
+    ref = TfxEngine(3, 3, 150.0, 20, n_envs=2, planes=2, env_id_offset=3)
+    ref.reset(ph[:2])
+    ref.set_regular(venv.cars_per_sec * venv.rate, seed=4)
+    ref.set_actions(cycle_period=6)
+    for _ in range(4):
+        venv.agent_step(n_ticks=10, cycle_period=6)
+        ref.step(10)
+    assert int(venv.engine.done_tick.max()) == 0           # (nothing overflowed, so nothing froze)
+    assert torch.equal(venv.engine.leading[3:5], ref.leading) and torch.equal(venv.engine.lastcar[3:5], ref.lastcar)
+    import math
+    cpt = venv.cars_per_sec * venv.rate
+    made = 40 // round(1 / cpt) * math.ceil(cpt) if round(1 / cpt) else 40 * math.ceil(cpt)
+    assert int(venv.cars_on_roads().sum()) > 0 and made > 0

@@ -172,3 +172,49 @@ def test_refresh_refuses_a_stale_staging_copy():
     fresh[0, 5, slot, 1] = 0.25      # the head car of road 5 slows down
     eng.refresh()
     assert float(eng.xv[0, 5, slot, 1]) == 0.25
+
+
+@pytest.mark.parametrize("call", ["step", "agent_step"])
+@pytest.mark.parametrize("path", ["split", "one_range"])
+def test_failed_launch_in_the_middle_of_a_sequence_leaves_a_usable_handle(call, path, monkeypatch):
+    """tfx_debug_fail_after makes the n-th launch of a call fail: the call returns TFX_EDEVICE with a message, and the
+    handle is as usable as before - the second stream joined back, agent mode / reward accumulation / the half being
+    enqueued restored (round-3 finding: early returns skipped all of that).  After reloading the state the same handle
+    reproduces an untouched handle's run bit for bit, in both kinds of call."""
+    monkeypatch.setenv("TFX_RESIDENT", "0")
+    monkeypatch.setenv("TFX_PAIRS", "2")
+    monkeypatch.setenv("TFX_TAIL", "2")
+    monkeypatch.setenv("TFX_SPLIT", "2" if path == "split" else "0")
+    a = wl.setup_engine("cfg1", envs=6)
+    b = wl.setup_engine("cfg1", envs=6)
+    snap = [t.clone() for t in (a.xv, a.leading, a.lastcar, a.obs, a.rewards, a.waiting, a.passed_dst)]
+
+    def restore(e):
+        e.reset(np.zeros((1, e.I), np.int32))
+        ring = e.xv
+        ring.copy_(snap[0])
+        for dst, src in zip((e.leading, e.lastcar, e.obs, e.rewards, e.waiting, e.passed_dst), snap[1:]):
+            dst.copy_(src)
+        e.refresh()
+
+    for n_fail in (1, 2, 3, 5, 8):
+        nat.check(a.lib.tfx_debug_fail_after(a.h, n_fail))
+        with pytest.raises(nat.TfxError, match="injected launch failure"):
+            if call == "step":
+                a.step(10)
+            else:
+                a.agent_step(10, remi=True)
+        torch.cuda.synchronize()
+        restore(a)
+        restore(b)
+        # plain ticks AND a fused decision on the handle that failed == the same on the untouched one
+        a.step(7)
+        b.step(7)
+        oa = [t.clone() for t in a.agent_step(6, remi=False)]
+        ob = [t.clone() for t in b.agent_step(6, remi=False)]
+        for x, y in zip(oa, ob):
+            assert torch.equal(x, y), (n_fail,)
+        for name in ("leading", "lastcar", "obs", "rewards", "waiting", "passed_dst"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (n_fail, name)
+        assert torch.equal(a.xv, b.xv), n_fail
+    nat.check(a.lib.tfx_debug_fail_after(a.h, 0))

@@ -155,3 +155,68 @@ def test_batched_stack_on_device_matches_single_env_stack():
                 assert bool(d) == bool(outs[k][2][e])
     finally:
         update_flags(**DEFAULTS)
+
+
+def test_batched_validate_metrics_match_the_reference_stack():
+    """Validate-mode metrics in batched form: `light_times` per decision (traffic_test.py:41-46),
+    trip times (traffic_env.py:139-157) and `unfinished` (util.py:91-92) from VecRemiRepeater(TrafficVecEnv(validate=
+    True)).  Env 0 of the batch is seeded like the reference run captured in stack_validate.npz and must reproduce it
+    - observations, Remi rewards, light times, trip times, unfinished cars, final ring indices; the other envs of the
+    batch (other seeds) must equal single-env stacks of this package built with those seeds."""
+    from gym_traffic.spaces.gspace import GSpace
+    z = np.load(os.path.join(GOLDEN_DIR, "wrappers", "stack_validate.npz"))
+    sc = json.loads(str(z["scenario"]))
+    E, I, n_dec = 3, sc["m"] * sc["n"], sc["decisions"]
+    ticks = int(sc["light_secs"] / 0.5)
+    try:
+        update_flags(**dict(DEFAULTS, mode='validate', local_cars_per_sec=float(sc["lcps"])))
+        # the reference run: np.random.seed(seed); reset() draws the initial phases, Repeater._reset one action
+        sp = GSpace([I], np.int32(2))
+        ph0, a0 = np.zeros((E, I), np.int32), np.zeros((E, I), np.int32)
+        for e in range(E):
+            np.random.seed(sc["seed"] + e)
+            ph0[e], a0[e] = sp.sample(), sp.sample()
+        rng = np.random.RandomState(77)
+        acts = rng.randint(2, size=(n_dec, E, I)).astype(np.int32)
+        acts[:, 0] = z["actions"]
+        venv = TrafficVecEnv(E, sc["m"], sc["n"], sc["L"], capacity=sc["C"], spawn='poisson', seed=sc["seed"],
+                             local_cars_per_sec=float(sc["lcps"]), validate=True)
+        stack = V.VecRemiRepeater(venv, ticks, remi=True)
+        stack.sample_actions = lambda: torch.as_tensor(a0).to(venv.engine.device)
+        first = stack.reset(ph0).cpu().numpy().copy()
+        assert np.array_equal(first[0], z["reset"])
+        lt = [[] for _ in range(E)]
+        outs = []
+        for k in range(n_dec):
+            o, r, d = stack.step(torch.as_tensor(acts[k]).to(venv.engine.device))
+            t = stack.info['light_times'].cpu().numpy()
+            for e in range(E):
+                lt[e].extend(t[e][t[e] != 0].astype(np.float64).tolist())
+            outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), d.cpu().numpy().copy()))
+            assert np.array_equal(outs[-1][0][0], z["obs"][k]), k
+            assert np.array_equal(outs[-1][1][0].astype(np.float64), z["rewards"][k]), k
+            assert bool(outs[-1][2][0]) == bool(z["done"][k]), k
+            assert len(lt[0]) == z["light_off"][k + 1], k
+        assert np.array_equal(np.asarray(lt[0]), z["light_times"])
+        assert np.array_equal(venv.trip_times(0).astype(np.float64), z["trip_times"])
+        unfinished = venv.unfinished().cpu().numpy()
+        assert int(unfinished[0]) == int(z["unfinished"])
+        assert np.array_equal(venv.engine.leading[0].cpu().numpy(), z["final_leading"])
+        assert np.array_equal(venv.engine.lastcar[0].cpu().numpy(), z["final_lastcar"])
+        trips = venv.trip_times()
+        for e in range(1, E):                       # the other envs: single-env stacks with their seeds
+            env = A.make_env(sc["m"], sc["n"], sc["L"], seed=sc["seed"] + e, capacity=sc["C"])
+            base = env.unwrapped
+            np.random.seed(sc["seed"] + e)
+            assert np.array_equal(np.array(env.reset()), first[e]), e
+            lte = []
+            for k in range(n_dec):
+                o, r, d, info = env.step(acts[k, e])
+                lte.extend(np.asarray(info['light_times'], np.float64).tolist())
+                assert np.array_equal(np.array(o), outs[k][0][e]), (e, k)
+                assert np.array_equal(np.asarray(r, np.float32), outs[k][1][e]), (e, k)
+            assert lte == lt[e], e
+            assert np.array_equal(np.asarray(base.trip_times, np.float32), trips[e]), e
+            assert int(np.sum(base.cars_on_roads())) == int(unfinished[e]), e
+    finally:
+        update_flags(**DEFAULTS)

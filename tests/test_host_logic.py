@@ -302,3 +302,22 @@ def test_pmc_summary_tells_the_move_kernels_apart():
     assert ps.short("void tfx::k_advance<true>(tfx::Dev, int)") == "k_advance"
     assert ps.short("void tfx::k_res<2, false>(tfx::Dev, tfx::ResArgs)") == "k_res"
     assert ps.short("void at::native::vectorized_elementwise_kernel<4>(int)") is None
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "_reg_" in n])
+def test_regular_mirror_counts_equal_the_reference_schedule(name, golden_cache):
+    """The host mirror of the on-device `regular` generator (tfx_set_regular) makes, tick for tick, as many cars as the
+    reference's generator did in the captured run (traffic_env.py:167-176); the entry roads come from the Philox stream
+    and are a uniform choice over the entry points."""
+    from gym_traffic.devrng import RegularMirror
+    g = golden_cache(name)
+    per_tick = np.diff(g["spawn_off"])
+    cpt = float(g["cars_per_sec"]) * g.sc["rate"]
+    n_entry = len(g["entrypoints"])
+    mir = RegularMirror(cpt, 99, n_entry, [0, 1, 7])
+    hist = np.zeros(n_entry, np.int64)
+    for t in range(len(per_tick)):
+        cnt = mir.next_tick()
+        assert (cnt.sum(axis=1) == per_tick[t]).all(), (name, t)
+        hist += cnt.sum(axis=0)
+    assert hist.min() > 0 and hist.max() < 3 * hist.sum() / n_entry

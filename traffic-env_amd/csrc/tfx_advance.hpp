@@ -182,7 +182,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
       if (ovf > 0) d.done_tick[env] = tick + 1;
       if (decide) d.greedy_act[(size_t)env * d.I + s] = greedy_decide(d, env, s);
     }
-    int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+    int *ob = d.lights + (size_t)env * d.lights_stride;
     ob[s] = ph_new;
     ob[d.I + s] = el_new;
   } else if (!serial) {
@@ -200,7 +200,7 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
           // the popped car's spawn tick: its ring slot, or row j of the road's outbox (transposed; <= 2 pops here)
           const float cw = !d.w ? 0.0f : (TL ? d.outw[ocol_of(d, env, x) + (size_t)j * 64] : d.w[(size_t)idx * d.C + ps]);
           if (d.trip_times && t < d.trip_cap)
-            d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - side_tick(d, cw)) / 2.0f;
+            d.trip_times[(size_t)env * d.trip_cap + t] = side_age(d, tick, cw) / 2.0f;
           ++t;
           ps = wrap1(ps + 1, d.C);
         }
@@ -217,13 +217,13 @@ template <bool TL, bool HET = false, bool GREEDY = false>
 __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx, const int only_risky) {
   // (behind k_tail the clock already stands past the pair: the tick is tickA - 1, whatever the restricted pass left in tickB)
   const int tick = only_risky ? *d.tickA - 1 : *d.tickB;
-  if (only_risky && *d.risk_any != tick) return;
+  if (only_risky && risk_any_word(d, tidx) != tick) return;
   const int per_env = d.I + (d.R - d.r);
   const long total = (long)d.E * per_env;
   for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
-    if (only_risky && d.env_risk[env] != tick) continue;
+    if (only_risky && risk_word(d, env, tidx) != tick) continue;
     if (gid == 0) *d.tickA = tick + 1;
     advance_item<TL, HET, GREEDY>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
   }

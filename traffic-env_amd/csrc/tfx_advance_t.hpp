@@ -166,7 +166,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
   auto trip = [&](float cw) {
     if (d.validate && d.n_trips) {
       const int t = d.n_trips[env];
-      if (d.trip_times && t < d.trip_cap) d.trip_times[(size_t)env * d.trip_cap + t] = ((float)tick - side_tick(d, cw)) / 2.0f;
+      if (d.trip_times && t < d.trip_cap) d.trip_times[(size_t)env * d.trip_cap + t] = side_age(d, tick, cw) / 2.0f;
       d.n_trips[env] = t + 1;
     }
   };

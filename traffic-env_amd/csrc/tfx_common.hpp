@@ -35,6 +35,10 @@ struct Dev {
   float2 *xv;  // [E][R][C] (x, v) per ring slot
   float *w;    // [E][R][C] spawn tick per ring slot, or nullptr
   int *leading, *lastcar, *obs;
+  // phase | elapsed of env k's intersections: lights + k * lights_stride (= obs + 2r, obs_len: the words inside obs
+  // - or a workgroup's LDS copy with stride 0, k_tail)
+  int *lights;
+  int lights_stride;
   float *rewards;
   int *waiting;
   uint8_t *passed_dst;
@@ -62,8 +66,15 @@ struct Dev {
   int layout;
   float *tailx;   // per road: x of the last car after the advance (what update_lights reads)
   int *env_flag;  // == tick+1 when the env must take the serial advance this tick
-  int *env_risk;  // == tick+1 when the env takes the pair of ticks starting at `tick` one tick at a time (k_risk)
-  int *risk_any;  // == tick+1 when k_risk marked any env for the pair starting at `tick`
+  // == tick+1 when the env takes the pair of ticks starting at `tick` one tick at a time (k_risk).  Two planes, used in
+  // turn by the pairs of a call (risk_word): k_tail stamps the NEXT pair's plane while the launches behind it still read
+  // the current pair's
+  int *env_risk;
+  int risk_stride;  // words from one plane to the other (the whole handle's E, also inside the half of a split call)
+  int4 *exp_pad;    // TFX_EXP_PAD=n (timing experiments): k_tail writes n extra 16-byte words per road here
+  int exp_pad_n;
+  int no_stamps;    // k_env: the workgroup decides about its env's pairs itself, the stamps are not consulted
+  int *risk_any;  // [2], one per plane of env_risk: == tick+1 when any env is marked for the pair starting at `tick`
   unsigned long long *veh;
   int *tickA, *tickB;
   // per-tick inputs
@@ -77,7 +88,7 @@ struct Dev {
   // whenever (t + 1) % greedy_spacing == 0
   int greedy_spacing;
   int *greedy_act;               // [E][I]
-  // heterogeneous cars (tfx_config.n_archetypes): every car's side word w holds 8 * spawn tick + table row
+  // heterogeneous cars (tfx_config.n_archetypes): every car's side word w holds (spawn tick mod 2^24) << 6 | table row as integer bits
   int het;
   const float *arch_tab;         // [TFX_MAX_ARCH][ARCH_W]: l, a, v0, T, s0, 2 sqrt(a b), delta, spawn speed
   int *taila;                    // per road: table row of its last car (next to tailx)
@@ -134,9 +145,30 @@ __device__ __forceinline__ void idm_step(const Dev &d, float x, float v, float x
 // ---- heterogeneous cars ---------------------------------------------------------------------------------
 constexpr int ARCH_W = 8;
 enum { AR_L = 0, AR_A, AR_V0, AR_T, AR_S0, AR_2SAB, AR_DELTA, AR_V };
-__device__ __forceinline__ int side_arch(float wa) { return ((int)wa) & (TFX_MAX_ARCH - 1); }
-__device__ __forceinline__ float side_tick(const Dev &d, float wa) { return d.het ? floorf(wa * 0.125f) : wa; }
-__device__ __forceinline__ float side_pack(float tick, int row) { return tick * 8.0f + (float)row; }
+// The side word of a heterogeneous car is an INTEGER bit pattern kept in the float plane: (spawn tick mod 2^24) << 6 |
+// table row.  (Round 3 stored the float value 8 * tick + row: exact only below 2^24, so from tick 2^21 on the row bits
+// were rounded away and new cars got wrong parameters.)  The pattern never has an all-ones exponent (bit 30 is clear),
+// loads, stores, moves and selects keep denormal patterns as they are, and no arithmetic ever touches the word.  Trip
+// times need only tick differences, taken modulo 2^24 (side_age) - they stay right however long the handle runs.
+constexpr int ARCH_BITS = 6;
+static_assert((1 << ARCH_BITS) == TFX_MAX_ARCH, "the side word holds the table row in its low bits");
+constexpr int SIDE_TICK_MASK = 0xffffff;
+__device__ __forceinline__ int side_arch(float wa) { return __float_as_int(wa) & (TFX_MAX_ARCH - 1); }
+__device__ __forceinline__ float side_tick(const Dev &d, float wa) {
+  return d.het ? (float)(__float_as_int(wa) >> ARCH_BITS) : wa;
+}
+__device__ __forceinline__ float side_pack(int tick, int row) {
+  return __int_as_float(((tick & SIDE_TICK_MASK) << ARCH_BITS) | row);
+}
+// tick - spawn tick of a car leaving the map (advance_hack, traffic_env.py:154)
+__device__ __forceinline__ float side_age(const Dev &d, int tick, float wa) {
+  return d.het ? (float)((tick - (__float_as_int(wa) >> ARCH_BITS)) & SIDE_TICK_MASK) : (float)tick - wa;
+}
+// the archetype table (rows past the handle's own are zero) into a workgroup's LDS copy
+__device__ __forceinline__ void load_arch(const Dev &d, float *s_arch) {
+  for (int i = threadIdx.x; i < TFX_MAX_ARCH * ARCH_W; i += blockDim.x) s_arch[i] = d.arch_tab[i];
+  __syncthreads();
+}
 
 // (v/v0)**delta for an integer delta in 1..8: oracle/idm_oracle.c powi_cr, multiply for multiply
 __device__ __forceinline__ float powi_cr(float q, int n) {
@@ -212,6 +244,13 @@ __device__ __forceinline__ void idm_step_fast(const Dev &d, float x, float v, fl
   vn = np_max0(v + dvr);
 }
 
+// the stamp of env for the pair that tick index `tidx` of the call belongs to (ticks 2p and 2p + 1: plane p & 1)
+__device__ __forceinline__ int &risk_word(const Dev &d, int env, int tidx) {
+  return d.env_risk[(size_t)((tidx >> 1) & 1) * d.risk_stride + env];
+}
+
+__device__ __forceinline__ int &risk_any_word(const Dev &d, int tidx) { return d.risk_any[(tidx >> 1) & 1]; }
+
 // env stopped for the rest of the current agent step: it overflowed in one of the step's earlier
 // ticks (done_tick holds overflow tick + 1)
 __device__ __forceinline__ bool env_frozen(const Dev &d, int env, int tick) {
@@ -242,7 +281,7 @@ __device__ __forceinline__ void light_next(const Dev &d, int env, int i, int tic
 }
 __device__ __forceinline__ void light_update(const Dev &d, int env, int i, int tick, int tidx,
                                              int &ph_new, int &el_new) {
-  const int *ob = d.obs + (size_t)env * d.obs_len + 2 * d.r;
+  const int *ob = d.lights + (size_t)env * d.lights_stride;
   light_next(d, env, i, tick, tidx, ob[i], ob[d.I + i], ph_new, el_new);
 }
 

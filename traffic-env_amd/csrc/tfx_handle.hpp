@@ -50,6 +50,11 @@ struct tfx_handle_s {
   int grid_edge = 0;
   int grid_adv = 0;
   int grid_tail = 0, grid_tail_half = 0;  // k_tail: workgroups of 256 lanes / of 128 (the halves of a split call)
+  int tail_threads = 256, tail_threads_half = 128;
+  // k_env (tfx_env.hpp): a workgroup per env for all the ticks of a call.  TFX_ENVK=0 never, 2 at any batch size
+  int envk = 0;  // (measured 35 % slower than pairs + k_tail at cfg2: off unless forced)
+  int grid_env = 0, env_threads = 0;
+  long long env_ticks = 0;    // ticks run by k_env since tfx_create
   int tail = 1;               // k_tail after a two-tick pass (tfx_tail.hpp): TFX_TAIL=0 never, 2 at any batch size
   // calls of pairs run as TWO halves of the env range, the second on a stream of the handle's own: the latency-bound
   // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)
@@ -86,7 +91,7 @@ struct tfx_handle_s {
   long long fused_ticks = 0;   // ticks run by k_res since tfx_create
   long long pair_ticks = 0;    // ticks run as two-tick passes since tfx_create
   long long tail_ticks = 0;    // ... of which k_tail finished the pair (tfx_tail.hpp)
-  long long ag_fused = 0, ag_pair = 0;  // what ONE replay of the captured agent-step graph adds to the two above
+  long long ag_fused = 0, ag_pair = 0, ag_env = 0;  // what ONE replay of the captured agent-step graph adds to the counters
   const char *step_kernel = "";  // the kernel that moved the cars in the last tick (tfx_step_kernel)
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;
@@ -104,6 +109,7 @@ struct tfx_handle_s {
   unsigned long long input_gen = 0;
   bool use_graph = true;  // TFX_GRAPH=0 disables
   bool size_only = false;
+  int fail_after = 0;  // tfx_debug_fail_after: the n-th launch from now fails (error-path tests); 0 = off
   // on-device Poisson arrivals / greedy controller (own buffers)
   bool poisson = false, greedy = false;
   int greedy_spacing = 3;
@@ -174,6 +180,16 @@ void build_slots(tfx_handle_s *h) {
   for (size_t s = 0; s < h->h_slot_road.size(); ++s)
     if (h->h_slot_road[s] >= 0) h->h_road_slot[h->h_slot_road[s]] = (int)s;
 }
+
+// fault injection for the error-path tests (tfx_debug_fail_after): true when THIS launch is the one to fail
+bool inject_failure(tfx_handle h) {
+  if (h->size_only || h->fail_after <= 0) return false;
+  return --h->fail_after == 0;
+}
+#define TFX_INJECT(h)                                                                              \
+  do {                                                                                             \
+    if (inject_failure(h)) return fail(TFX_EDEVICE, "injected launch failure (tfx_debug_fail_after)"); \
+  } while (0)
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

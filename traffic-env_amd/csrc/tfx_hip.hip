@@ -27,24 +27,27 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
-  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
+  const bool envk = !res_usable(h, n_ticks) && env_usable(h, n_ticks);
+  const bool split = !envk && !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
   if (split) {
     if (int rc = ensure_split(h, st)) return rc;
   }
-  if (!h->use_graph || split) {
-    long long nf = 0, np = 0;
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np, split);
+  // (a batch big enough for either is not bound by its launches: enqueued eagerly)
+  if (!h->use_graph || split || (envk && h->envk != 2)) {
+    long long nf = 0, np = 0, ne = 0;
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np, ne, split, envk);
     if (rc == TFX_OK) {
       h->fused_ticks += nf;
       h->pair_ticks += np;
+      h->env_ticks += ne;
       if (split) h->split_ticks += n_ticks;
     }
     return rc;
   }
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[640];
-  snprintf(key, sizeof key, "%llu|%u|%u|%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
-           h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, (int)h->poisson,
+  snprintf(key, sizeof key, "%d|%llu|%u|%u|%d.%d.%d.%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
+           (int)envk, h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, h->ps.regular, h->ps.every, h->ps.burst, (int)h->poisson,
            (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, (void *)aobs,
            (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
            (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
@@ -61,6 +64,11 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       (void)launch_advance(h, 0, nullptr);
       h->size_only = false;
     }
+    if (envk) {
+      h->size_only = true;
+      (void)launch_env(h, n_ticks, nullptr, true);
+      h->size_only = false;
+    }
     if (!res_usable(h, n_ticks) && pairs_usable(h)) {
       h->size_only = true;
       (void)launch_move_tt<true, true>(h, 0, nullptr);
@@ -70,7 +78,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       (void)edge_grid(h);
     }
     HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream, h->ag_fused, h->ag_pair);
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream, h->ag_fused, h->ag_pair, h->ag_env, false, envk);
     hipGraph_t g = nullptr;
     const hipError_t ce = hipStreamEndCapture(h->ag_stream, &g);
     if (rc != TFX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -82,6 +90,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   HIPCHK(hipGraphLaunch(h->ag_exec, st));
   h->fused_ticks += h->ag_fused;  // (the capture ran no kernel: every replay counts)
   h->pair_ticks += h->ag_pair;
+  h->env_ticks += h->ag_env;
   return TFX_OK;
 }
 
@@ -136,6 +145,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
   if (const char *tv = getenv("TFX_TAIL")) h->tail = atoi(tv);
   if (const char *sv = getenv("TFX_SPLIT")) h->split = atoi(sv);
+  if (const char *kv = getenv("TFX_ENVK")) h->envk = atoi(kv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -205,7 +215,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec2 = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int4) : 0), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
-  const size_t o_risk = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
+  const size_t o_risk = off;  off = align_up(off + 2 * (size_t)d.E * sizeof(int), 256);
   d.trows = d.C - 2;  // (padding the tile stride off the power of two was measured: slightly slower)
   const size_t n_tpairs = (size_t)d.E * d.G * (size_t)d.trows * 64;  // (x, v) pairs of a transposed array
   // outbox: TFX_KP rows per tile (the cars a road hands over in a tick; round 1 kept a T-sized one)
@@ -233,6 +243,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
   d.env_risk = (int *)(base + o_risk);
+  d.risk_stride = d.E;
   d.outb = (float2 *)(base + o_outb);
   d.outw = (float *)(base + o_outw);
   d.leadx = (float *)(base + o_lead);
@@ -260,8 +271,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tickA = (int *)(base + o_misc + 16);
   d.tickB = (int *)(base + o_misc + 32);
   d.agent_first = (const int *)(base + o_misc + 48);
-  d.risk_any = (int *)(base + o_misc + 56);
-  h->tick2 = (int *)(base + o_misc + 64);
+  d.risk_any = (int *)(base + o_misc + 56);   // two words
+  h->tick2 = (int *)(base + o_misc + 64);     // tickA, tickB, risk_any[2] of the second half
   // reciprocal division is used only if it is exact for this handle's constants on the whole
   // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
   d.fastdiv = 0;
@@ -285,6 +296,10 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
     unsigned nbad = 1;
     if (hipMemcpy(&nbad, bad, sizeof nbad, hipMemcpyDeviceToHost) == hipSuccess && nbad == 0) d.fastmax = 1;
     (void)hipMemset(bad, 0, 8);
+  }
+  if (const char *pv = getenv("TFX_EXP_PAD")) {  // timing experiments only: extra bytes per road for k_tail to write
+    const int n = atoi(pv);
+    if (n > 0 && hipMalloc((void **)&d.exp_pad, (size_t)n * ER * sizeof(int4)) == hipSuccess) d.exp_pad_n = n;
   }
   d.action_mode = TFX_ACTION_CYCLE;
   d.action_period = 20;
@@ -348,6 +363,7 @@ int tfx_bind_buffers(tfx_handle h, const tfx_buffers *b) {
   Dev &d = h->d;
   d.xv = reinterpret_cast<float2 *>(b->xv); d.w = b->w;
   d.leading = b->leading; d.lastcar = b->lastcar; d.obs = b->obs;
+  d.lights = b->obs + 2 * d.r; d.lights_stride = d.obs_len;
   d.rewards = b->rewards; d.waiting = b->waiting; d.passed_dst = b->passed_dst;
   d.done_tick = b->done_tick; d.trip_times = b->trip_times; d.n_trips = b->n_trips;
   d.trip_cap = b->trip_cap;
@@ -478,6 +494,7 @@ int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uin
   h->ps.draws = (unsigned *)(base + n_counts + d.E);
   h->ps.cdf = (const unsigned *)(base + n_counts + 2 * (size_t)d.E);
   h->ps.n_cdf = n_cdf;
+  h->ps.regular = h->ps.every = h->ps.burst = 0;
   h->ps.seed_lo = (unsigned)seed;
   h->ps.seed_hi = (unsigned)(seed >> 32);
   HIPCHK(hipMemset(h->ps.gap_left, 0xff, (size_t)d.E * 4));  // -1: first gap not drawn yet
@@ -487,6 +504,37 @@ int tfx_set_poisson(tfx_handle h, double cars_per_tick, uint64_t seed, const uin
   d.spawn_mode = TFX_SPAWN_COUNTS;
   h->spawn_per_tick = 0;
   h->poisson = true;
+  return TFX_OK;
+}
+
+int tfx_set_regular(tfx_handle h, int32_t every, int32_t burst, uint64_t seed) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (every < 0 || burst < 1) return fail(TFX_EINVAL, "every must be >= 0 and burst >= 1");
+  Dev &d = h->d;
+  if (d.n_entry < 1) return fail(TFX_EINVAL, "no entry roads");
+  ++h->input_gen;
+  if (h->dev_ps) { (void)hipFree(h->dev_ps); h->dev_ps = nullptr; }
+  long rows = ((long)32 << 20) / ((long)d.E * d.n_entry * 4);
+  h->poisson_rows = (int)(rows < 1 ? 1 : (rows > 64 ? 64 : rows));
+  const size_t n_counts = (size_t)h->poisson_rows * d.E * d.n_entry;
+  const size_t bytes = (n_counts + 2 * (size_t)d.E) * 4;
+  HIPCHK(hipMalloc(&h->dev_ps, bytes));
+  HIPCHK(hipMemset(h->dev_ps, 0, bytes));  // (tick counters and car indices start at 0)
+  int *base = (int *)h->dev_ps;
+  h->ps = PoissonDev{};
+  h->ps.counts = base;
+  h->ps.gap_left = base + n_counts;
+  h->ps.draws = (unsigned *)(base + n_counts + d.E);
+  h->ps.seed_lo = (unsigned)seed;
+  h->ps.seed_hi = (unsigned)(seed >> 32);
+  h->ps.regular = 1;
+  h->ps.every = every;
+  h->ps.burst = burst;
+  d.spawn = h->ps.counts;
+  d.spawn_stride = 0;
+  d.spawn_mode = TFX_SPAWN_COUNTS;
+  h->spawn_per_tick = 0;
+  h->poisson = true;  // (an arrival stream drawn on the device: every path of tfx_set_poisson serves it)
   return TFX_OK;
 }
 
@@ -514,12 +562,17 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     // the arrivals of the whole call (in chunks of the rows the count buffer holds) in ONE launch each: they depend
     // on nothing but the stream, and a launch per tick was the longest one of a cfg4 tick
     int rc = TFX_OK;
+    // a chunk's kernels count ticks from 0 (row t of the count buffer is the chunk's tick t); a per-tick ACTION buffer is
+    // indexed by the tick of the whole call, so its base moves along with the chunks
+    const int *const act0 = h->d.action;
     for (int done = 0; done < n_ticks && rc == TFX_OK;) {
       const int chunk = n_ticks - done < h->poisson_rows ? n_ticks - done : h->poisson_rows;
       rc = launch_poisson(h, chunk, st);
       h->d.spawn_stride = (long)h->d.E * h->d.n_entry;
+      if (act0 && h->action_per_tick) h->d.action = act0 + (size_t)done * h->d.action_stride;
       if (rc == TFX_OK) rc = step_chunk(h, chunk, st);
       h->d.spawn_stride = 0;
+      h->d.action = act0;
       done += chunk;
     }
     return rc;
@@ -694,6 +747,12 @@ int tfx_tail_ticks(tfx_handle h, int64_t *ticks) {
   return TFX_OK;
 }
 
+int tfx_env_ticks(tfx_handle h, int64_t *ticks) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (ticks) *ticks = h->env_ticks;
+  return TFX_OK;
+}
+
 int tfx_split_ticks(tfx_handle h, int64_t *ticks) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->split_ticks;
@@ -701,6 +760,12 @@ int tfx_split_ticks(tfx_handle h, int64_t *ticks) {
 }
 
 const char *tfx_step_kernel(tfx_handle h) { return h ? h->step_kernel : ""; }
+
+int tfx_debug_fail_after(tfx_handle h, int32_t n_launches) {
+  if (int rc = check_handle(h, false)) return rc;
+  h->fail_after = n_launches > 0 ? n_launches : 0;
+  return TFX_OK;
+}
 
 int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_per_road) {
   if (int rc = check_handle(h, false)) return rc;

@@ -10,6 +10,7 @@
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_tail.hpp"
+#include "tfx_env.hpp"
 
 namespace {
 
@@ -44,6 +45,7 @@ int launch_dma(tfx_handle h, int tidx, hipStream_t st) {
     h->grid_move = move_grid(h, kern, 256, h->move_lds);
   }
   if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
   hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), h->move_lds, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -54,6 +56,7 @@ int launch_generic(tfx_handle h, int tidx, hipStream_t st) {
   h->step_kernel = "k_move";
   if (h->grid_move == 0) h->grid_move = move_grid(h, k_move<WPR>, 256 / (64 * WPR));
   if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
   hipLaunchKernelGGL(k_move<WPR>, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -66,6 +69,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
   auto go = [&](auto kern) {
     if (h->grid_move == 0) h->grid_move = move_grid(h, kern, 256);
     if (h->size_only) return (int)TFX_OK;
+    TFX_INJECT(h);
     hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(256), 0, st, h->d, tidx);
     HIPCHK(hipGetLastError());
     return (int)TFX_OK;
@@ -86,6 +90,7 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     auto gs = [&](auto kern, int threads = 256) {
       if (h->grid_move == 0) h->grid_move = (int)(tiles < (long)h->n_cu * 8 ? tiles : (long)h->n_cu * 8);
       if (h->size_only) return (int)TFX_OK;
+    TFX_INJECT(h);
       hipLaunchKernelGGL(kern, dim3(h->grid_move), dim3(threads), 0, st, h->d, tidx);
       HIPCHK(hipGetLastError());
       return (int)TFX_OK;
@@ -263,6 +268,7 @@ bool res_usable(tfx_handle h, int n_ticks) {
 int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi = 0, float *aobs = nullptr,
                float *areward = nullptr, uint8_t *adone = nullptr) {
   const Dev &d = h->d;
+  TFX_INJECT(h);
   ResArgs a;
   a.tail = tail;
   a.remi = remi;
@@ -310,6 +316,7 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
     h->grid_adv = (int)(g < 1 ? 1 : g);
   }
   if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
   const bool g = h->greedy;
   if (h->het) {
     if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
@@ -376,6 +383,7 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   }
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
   long grid = (long)resident * 10 / 6;
   if (const char *pc = getenv("TFX_MOVE_BLOCKS_PER_CU")) grid = atoi(pc) > 0 ? (long)atoi(pc) * h->n_cu : grid;
   const long need = ((long)h->d.E * h->d.G + 3) / 4;
@@ -407,6 +415,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   s.leading = d.leading + L * R;
   s.lastcar = d.lastcar + L * R;
   s.obs = d.obs + L * (size_t)d.obs_len;
+  s.lights = s.obs + 2 * d.r;
   s.rewards = d.rewards + L * I;
   s.waiting = d.waiting + L * r;
   s.passed_dst = d.passed_dst + L * I;
@@ -415,6 +424,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   if (d.n_trips) s.n_trips = d.n_trips + L;
   s.rec = d.rec + L * R;
   s.rec2 = d.rec2 + L * R;
+  if (d.exp_pad) s.exp_pad = d.exp_pad + L * R;
   s.tailx = d.tailx + L * R;
   if (d.taila) s.taila = d.taila + L * R;
   if (d.spawn_arch) s.spawn_arch = d.spawn_arch + L * (size_t)d.n_entry * (size_t)d.spawn_arch_S;
@@ -435,11 +445,14 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
 }
 
 // k_tail (tfx_tail.hpp) replaces k_advance(t) k_edge(t+1) k_advance(t+1) behind a two-tick pass: one workgroup per
-// env.  Not when the arrivals of t+1 are produced by a launch between the two ticks (the Poisson stream tick by tick:
-// agent steps; tfx_step generates them up front), and not below one env per CU (a handful of big envs - cfg4 - has
-// too few workgroups to offer).  (The greedy controller decides inside the advance.)
+// env, the env's ring words staged in LDS.  Not when the arrivals of t+1 are produced by a launch between the two ticks
+// (the Poisson stream tick by tick: agent steps; tfx_step generates them up front), not below one env per CU (a handful
+// of big envs - cfg4 - has too few workgroups to offer), and not when an env's words do not fit a workgroup's LDS.
+// (The greedy controller decides inside the advance.)
+constexpr size_t TAIL_LDS_MAX = (size_t)160 * 1024;
 bool tail_usable(tfx_handle h) {
   if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1) return false;
+  if (tail_lds_bytes(h->d.R, h->d.I, h->het) > TAIL_LDS_MAX) return false;
   return h->tail == 2 || h->d.E >= h->n_cu;
 }
 
@@ -454,47 +467,125 @@ bool split_usable(tfx_handle h, int n_ticks) {
   return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
 }
 
-// Workgroup size (the kernel takes any multiple of 64).  Alone on the chip 256 lanes and as many workgroups as fit are
-// best (measured at cfg2 against 128 / 192 / 320 / 384 / 512 / 1024 lanes: 0.091 ms per tick against 0.096 / 0.113 /
-// 0.098 / 0.119 / 0.090-0.131 - the launch lives on wavefronts in flight).  As one half of a split call, next to the
-// other half's pass, SMALLER workgroups win: they fit the gaps the pass leaves (vehicle-updates per second of the whole
-// call, same box: 64 lanes 5.15-5.18e11, 128 lanes 5.24-5.32e11, 192 5.10e11, 256 5.03-5.09e11, 320 4.76e11, 384 4.72e11).
-int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false) {
+// Workgroup size (the kernel takes any multiple of 64; TFX_TAIL_THREADS / TFX_TAIL_THREADS_HALF override for sweeps).
+// Round 3's unstaged k_tail: alone on the chip 256 lanes and as many workgroups as fit were best; as one half of a
+// split call, next to the other half's pass, 128 lanes (they fit the gaps the pass leaves).
+template <bool GREEDY, bool AGENT, bool W, bool HET>
+int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int risk_next) {
+  auto kern = k_tail<GREEDY, AGENT, W, HET>;
+  const size_t lds = tail_lds_bytes(h->d.R, h->d.I, HET);
+  // The attribute belongs to the FUNCTION, not to the handle: only ever raised (see res_try)
+  static size_t granted = 64 * 1024;
+  if (lds > granted) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted = lds;
+  }
   if (h->grid_tail == 0) {
     for (int half = 0; half < 2; ++half) {
-      const int threads = half ? 128 : 256;
+      int threads = half ? 128 : 256;
+      if (const char *tv = getenv(half ? "TFX_TAIL_THREADS_HALF" : "TFX_TAIL_THREADS"))
+        if (atoi(tv) >= 64 && atoi(tv) <= 256 && atoi(tv) % 64 == 0) threads = atoi(tv);
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_tail<false, false>), threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-      if (per_cu > (half ? 10 : 5) && h->greedy) per_cu = half ? 10 : 5;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (const char *pc = getenv("TFX_TAIL_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
       long g = (long)h->n_cu * per_cu;
       if (g > h->d.E) g = h->d.E;
       (half ? h->grid_tail_half : h->grid_tail) = (int)(g < 1 ? 1 : g);
+      (half ? h->tail_threads_half : h->tail_threads) = threads;
     }
   }
   if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
   const bool halves = h->split_half >= 0;
-  const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? 128 : 256);
-  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
-  switch (sel) {
-    case 12: hipLaunchKernelGGL((k_tail<false, false, true, true>), g, b, 0, st, h->d, tidx); break;
-    case 13: hipLaunchKernelGGL((k_tail<true, false, true, true>), g, b, 0, st, h->d, tidx); break;
-    case 14: hipLaunchKernelGGL((k_tail<false, true, true, true>), g, b, 0, st, h->d, tidx); break;
-    case 15: hipLaunchKernelGGL((k_tail<true, true, true, true>), g, b, 0, st, h->d, tidx); break;
-    case 0: hipLaunchKernelGGL((k_tail<false, false, false>), g, b, 0, st, h->d, tidx); break;
-    case 1: hipLaunchKernelGGL((k_tail<true, false, false>), g, b, 0, st, h->d, tidx); break;
-    case 2: hipLaunchKernelGGL((k_tail<false, true, false>), g, b, 0, st, h->d, tidx); break;
-    case 3: hipLaunchKernelGGL((k_tail<true, true, false>), g, b, 0, st, h->d, tidx); break;
-    case 4: hipLaunchKernelGGL((k_tail<false, false, true>), g, b, 0, st, h->d, tidx); break;
-    case 5: hipLaunchKernelGGL((k_tail<true, false, true>), g, b, 0, st, h->d, tidx); break;
-    case 6: hipLaunchKernelGGL((k_tail<false, true, true>), g, b, 0, st, h->d, tidx); break;
-    default: hipLaunchKernelGGL((k_tail<true, true, true>), g, b, 0, st, h->d, tidx); break;
-  }
+  const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? h->tail_threads_half : h->tail_threads);
+  hipLaunchKernelGGL(kern, g, b, lds, st, h->d, tidx, risk_next);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
+int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false, int risk_next = 0) {
+  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
+  switch (sel) {
+    case 12: return launch_tail_as<false, false, true, true>(h, tidx, st, risk_next);
+    case 13: return launch_tail_as<true, false, true, true>(h, tidx, st, risk_next);
+    case 14: return launch_tail_as<false, true, true, true>(h, tidx, st, risk_next);
+    case 15: return launch_tail_as<true, true, true, true>(h, tidx, st, risk_next);
+    case 0: return launch_tail_as<false, false, false, false>(h, tidx, st, risk_next);
+    case 1: return launch_tail_as<true, false, false, false>(h, tidx, st, risk_next);
+    case 2: return launch_tail_as<false, true, false, false>(h, tidx, st, risk_next);
+    case 3: return launch_tail_as<true, true, false, false>(h, tidx, st, risk_next);
+    case 4: return launch_tail_as<false, false, true, false>(h, tidx, st, risk_next);
+    case 5: return launch_tail_as<true, false, true, false>(h, tidx, st, risk_next);
+    case 6: return launch_tail_as<false, true, true, false>(h, tidx, st, risk_next);
+    default: return launch_tail_as<true, true, true, false>(h, tidx, st, risk_next);
+  }
+}
+
+// k_env (tfx_env.hpp): one workgroup per env takes the env through ALL the ticks of a call - the cars streamed from
+// HBM, the ring words in LDS.  For calls of two ticks or more on the transposed layout when an env's words fit a
+// workgroup's LDS, the inputs of every tick exist before the call (not the Poisson stream tick by tick: agent steps),
+// and there are enough envs to fill the chip with whole workgroups (below that the tiles of k_move_tt spread better).
+bool env_usable(tfx_handle h, int n_ticks) {
+  const Dev &d = h->d;
+  if (!h->envk || d.layout != 1 || n_ticks < 2 || h->move_variant != 0 || h->res_epb > 0 || !h->pairs) return false;
+  if (h->poisson && d.spawn_stride == 0) return false;
+  if (env_lds_bytes(d.R, d.I, h->het) > TAIL_LDS_MAX) return false;
+  return h->envk == 2 || d.E >= 2 * h->n_cu;
+}
+
+template <bool GREEDY, bool AGENT, bool W, bool HET>
+int launch_env_as(tfx_handle h, int n_ticks, hipStream_t st) {
+  auto kern = k_env<GREEDY, AGENT, W, HET>;
+  const size_t lds = env_lds_bytes(h->d.R, h->d.I, HET);
+  static size_t granted = 64 * 1024;  // (the attribute belongs to the function: only ever raised, see res_try)
+  if (lds > granted) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted = lds;
+  }
+  if (h->grid_env == 0) {
+    int threads = 64 * ENV_WAVES;
+    if (const char *tv = getenv("TFX_ENV_THREADS"))
+      if (atoi(tv) >= 64 && atoi(tv) <= ENV_MAX_THREADS && atoi(tv) % 64 == 0) threads = atoi(tv);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (const char *pc = getenv("TFX_ENV_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
+    long g = (long)h->n_cu * per_cu;
+    if (g > h->d.E) g = h->d.E;
+    h->grid_env = (int)(g < 1 ? 1 : g);
+    h->env_threads = threads;
+  }
+  if (h->size_only) return TFX_OK;
+  TFX_INJECT(h);
+  h->step_kernel = "k_env";
+  hipLaunchKernelGGL(kern, dim3(h->grid_env), dim3(h->env_threads), lds, st, h->d, n_ticks);
+  HIPCHK(hipGetLastError());
+  // every workgroup reads the clock at its start: it moves in a launch of its own
+  hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, h->d, n_ticks);
+  HIPCHK(hipGetLastError());
+  return TFX_OK;
+}
+
+int launch_env(tfx_handle h, int n_ticks, hipStream_t st, bool agent = false) {
+  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
+  switch (sel) {
+    case 12: return launch_env_as<false, false, true, true>(h, n_ticks, st);
+    case 13: return launch_env_as<true, false, true, true>(h, n_ticks, st);
+    case 14: return launch_env_as<false, true, true, true>(h, n_ticks, st);
+    case 15: return launch_env_as<true, true, true, true>(h, n_ticks, st);
+    case 0: return launch_env_as<false, false, false, false>(h, n_ticks, st);
+    case 1: return launch_env_as<true, false, false, false>(h, n_ticks, st);
+    case 2: return launch_env_as<false, true, false, false>(h, n_ticks, st);
+    case 3: return launch_env_as<true, true, false, false>(h, n_ticks, st);
+    case 4: return launch_env_as<false, false, true, false>(h, n_ticks, st);
+    case 5: return launch_env_as<true, false, true, false>(h, n_ticks, st);
+    case 6: return launch_env_as<false, true, true, false>(h, n_ticks, st);
+    default: return launch_env_as<true, true, true, false>(h, n_ticks, st);
+  }
+}
+
 template <bool AGENT>
 int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
+  TFX_INJECT(h);
   if (h->d.het) hipLaunchKernelGGL((k_edge<AGENT, true, true>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   else if (h->d.w) hipLaunchKernelGGL((k_edge<AGENT, true>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   else hipLaunchKernelGGL((k_edge<AGENT, false>), dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
@@ -503,6 +594,7 @@ int launch_edge(tfx_handle h, int tidx, hipStream_t st) {
 }
 
 int launch_risk(tfx_handle h, int tidx, hipStream_t st) {
+  TFX_INJECT(h);
   hipLaunchKernelGGL(k_risk, dim3(edge_grid(h)), dim3(256), 0, st, h->d, tidx);
   HIPCHK(hipGetLastError());
   return TFX_OK;

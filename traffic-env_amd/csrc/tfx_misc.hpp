@@ -95,7 +95,7 @@ __global__ void k_import_ring(const Dev d, const float2 *ring, const float *ring
       d.xv[tpos(d, (int)id, k)] = row[slot];
       if (d.w && (ringw || (d.het && ringa))) {
         const float tk = ringw ? ringw[(size_t)id * d.C + slot] : 0.0f;
-        d.w[tpos(d, (int)id, k)] = d.het ? side_pack(tk, ringa ? (ringa[(size_t)id * d.C + slot] & (TFX_MAX_ARCH - 1)) : 0) : tk;
+        d.w[tpos(d, (int)id, k)] = d.het ? side_pack((int)tk, ringa ? (ringa[(size_t)id * d.C + slot] & (TFX_MAX_ARCH - 1)) : 0) : tk;
       }
     }
     d.leadx[id] = row[ld].x;
@@ -173,6 +173,10 @@ struct PoissonDev {
   const unsigned *cdf;     // [n_cdf] thresholds
   int n_cdf;
   unsigned seed_lo, seed_hi;
+  // The reference's `regular` generator instead (traffic_env.py:167-176, tfx_set_regular): `burst` cars in every
+  // tick i with i % every == 0 (every tick when every == 0), i = ticks the env's generator has run - kept in
+  // gap_left; car c (0-based, counted in draws) takes its entry road from the same draw 1 + 2c as a Poisson car
+  int regular, every, burst;
 };
 
 // Draw indexing (fixed, so the stream is random-access): draw 0 = the first gap; car c (0-based)
@@ -204,7 +208,17 @@ __global__ __launch_bounds__(1024) void k_poisson(const Dev d, const PoissonDev 
     for (int t = 0; t < n_ticks; ++t) {
       for (int j = tid; j < d.n_entry; j += nthr) s_hist[j] = 0;
       __syncthreads();
-      if (!frozen) {
+      if (!frozen && ps.regular) {
+        const bool due = ps.every == 0 || gap % ps.every == 0;
+        ++gap;
+        if (due) {
+          for (int j = tid; j < ps.burst; j += nthr) {
+            philox4x32(1u + 2u * (c0 + (unsigned)j), gid, 0x524F4144u, 0u, ps.seed_lo, ps.seed_hi, u);
+            atomicAdd(&s_hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
+          }
+          c0 += (unsigned)ps.burst;
+        }
+      } else if (!frozen) {
         if (gap < 0) gap = gap_of(0u);
         if (gap > 0) {
           --gap;

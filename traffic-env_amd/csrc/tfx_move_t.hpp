@@ -52,10 +52,7 @@ template <int P, int NT = 0, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
-  if (HET) {
-    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
-    __syncthreads();
-  }
+  if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
@@ -211,7 +208,7 @@ __global__ __launch_bounds__(256) void k_move_t(const Dev d, const int tidx) {
             const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
             const float start = (lc != p.ld) ? (tx - s_arch[ta * ARCH_W + AR_L]) - s_arch[ta * ARCH_W + AR_S0] : INFINITY;
             const float xs = (start < 0.0f) ? start : 0.0f;
-            step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack((float)tick, row));
+            step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack(tick, row));
             lc = wrap1(lc + 1, C);
             tx = xs;
             ta = row;

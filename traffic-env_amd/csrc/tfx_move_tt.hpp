@@ -67,245 +67,253 @@ namespace tfx {
 // HET (implies W): heterogeneous cars, as in k_move_t - the side word is 8 * spawn tick + the car's row of the archetype
 // table (LDS copy); a car's own row gives its IDM parameters in BOTH of its ticks, its leader's row the length the gap
 // subtracts (the walk carries the lengths of cars k-1 and k-2 along with their new states)
+// One tile (64 roads of one env, lane = road) of a pass: every car through tick `tick` and - `two` - all but the roads'
+// heads and joiners through tick + 1 as well.  Returns the lane's vehicle-updates of tick `tick`.  Reads and writes the
+// ring words (leading, lastcar, tailx, rec, the light words) through `d`: the arrays themselves (k_move_tt) or a
+// workgroup's LDS copies of one env's (k_env, tfx_env.hpp).
+template <bool TWO, bool AGENT, bool W, bool HET>
+__device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const int env, const int lane, const int tick,
+                                            const int tick_sp, const int tidx, const bool two, const float *s_arch) {
+  constexpr int P = TT_P;
+  const int C = d.C;
+  const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+  const bool valid = e_slot >= 0;
+  const int e = valid ? e_slot : 0;
+  const int id = env * d.R + e;
+  const bool run = valid && !(AGENT && env_frozen(d, env, tick));
+  const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
+  const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
+  const int n_old = run ? p.n_old : 0;
+  const int n_sp = run ? p.n_tot - p.n_old : 0;
+
+  float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;  // written: row k of this road = col[k * 64]
+  const float2 *colr = col + (size_t)hb * 64;                 // read: the live rows start hb rows down
+  float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
+  float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;  // side words: same rows as col
+  float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
+
+  int kmax = n_old;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(kmax, off, 64);
+    kmax = o > kmax ? o : kmax;
+  }
+  kmax = __builtin_amdgcn_readfirstlane(kmax);
+
+  float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
+  float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
+  float y1w = 0.0f;                                      // side word of car k-1
+  float y1l = 0.0f, y2l = 0.0f;                          // HET: lengths of cars k-1 and k-2
+  int last_a = 0;                                        // HET: table row of the last car processed (the road's tail)
+  int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
+  bool open = true, far = false;
+  bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
+  float2 *wp = col;  // where the next surviving car goes: one row further down per survivor
+  int kq1 = 0x7fffffff;  // tick t+1 tests x instead of v from this car on (index of tick t)
+  float tail_x = 0.0f, tail_z = 0.0f;
+  const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
+
+  auto ld2 = [&](const float2 *ptr) {
+    const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ptr));
+    return make_float2(t.x, t.y);
+  };
+  auto st2 = [&](float2 *ptr, float a, float b) {
+    f2v t;
+    t.x = a;
+    t.y = b;
+    __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(ptr));
+  };
+  // Car k of this lane's road through tick t, car k-1 through tick t+1.  `last` (a compile-time flag): only
+  // the second half, for the road's last car.
+  auto step = [&](int k, float x, float v, float sw, auto last) {
+    constexpr bool LAST = decltype(last)::value;
+    float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
+    // (one wave-wide test per row.  Round 3 measured the alternatives on this kernel: the speeds read from memory
+    // tested once per group of P rows, 0.772 ms per pass against 0.764; no test at all - results wrong - 0.734)
+    const bool bad = !HET && ((!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v)));
+    const bool off_domain = !HET && __builtin_amdgcn_ballot_w64(bad) != 0ull;
+    float my_l = d.car_l;
+    if (HET) {
+      if (!LAST) {
+        last_a = side_arch(sw);
+        const float *me = s_arch + last_a * ARCH_W;
+        idm_step_het(d, me, x, v, xprev, vprev, llv, xn, vn);
+        my_l = me[AR_L];
+      }
+      if (TWO) idm_step_het(d, s_arch + side_arch(y1w) * ARCH_W, y1x, y1v, y2x, y2v, y2l, zx, zv);
+    } else if (d.fastdiv && !off_domain) {
+      if (!LAST) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
+      if (TWO) idm_step_fast(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
+    } else {
+      if (!LAST) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
+      if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
+    }
+    if (TWO && two && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
+      st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
+      if (W) wcol[wp - col] = y1w;
+      wp += 64;
+      if (pend_int) {
+        const float wq1 = (k - 1 >= kq1) ? zx : zv;
+        n_wait1 += (wq1 < d.thresh) ? 1 : 0;
+        n_det1 += (zx > d.near_end) ? 1 : 0;
+        if (LAST) tail_z = zx;  // (the road's last car is flushed by the LAST call)
+      }
+    }
+    if (LAST) return;
+    xprev = x;
+    vprev = v;
+    llv = my_l;
+    const bool was_open = open;
+    const bool pop = open && (xn > d.length);  // the while loop of :123
+    open = pop;
+    if (pop) {
+      if (kpop < KP) {
+        ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+        if (W) owcol[(size_t)kpop * 64] = sw;
+      } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
+        st2(&col[(size_t)k * 64], xn, vn);
+        if (W) wcol[(size_t)k * 64] = sw;
+        wp = col + (size_t)(k + 1) * 64;
+      }
+      far = far || ((xn - d.length) > d.length);
+      ++kpop;
+    } else if (TWO && two) {
+      pend = true;
+      pend_int = !was_open;
+      if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
+    } else {
+      st2(wp, xn, vn);
+      if (W) wcol[wp - col] = sw;
+      wp += 64;
+    }
+    const float wq = (k >= kq) ? xn : vn;
+    n_wait += (wq < d.thresh) ? 1 : 0;
+    n_det += (xn > d.near_end) ? 1 : 0;
+    if (!TWO) tail_x = xn;  // (a pair: y1 holds the last car's new state when the walk ends)
+    y2x = y1x;
+    y2v = y1v;
+    y1x = xn;
+    y1v = vn;
+    if (W) y1w = sw;
+    if (HET) {
+      y2l = y1l;
+      y1l = my_l;
+    }
+  };
+
+  // ---- cars in memory: rows 0 .. kmax-1 of the live part, P rows in flight --------------------
+  float2 pf[P];
+  float pfw[P];
+  const float *wcolr = wcol + (size_t)hb * 64;
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    pf[u] = (u < n_old) ? ld2(&colr[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
+    pfw[u] = (W && u < n_old) ? wcolr[(size_t)u * 64] : 0.0f;
+  }
+  for (int k0 = 0; k0 < kmax; k0 += P) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int k = k0 + u;
+      if (k < kmax) {
+        const float2 cur = pf[u];
+        const float curw = pfw[u];
+        if (k + P < kmax) {
+          pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+          pfw[u] = (W && k + P < n_old) ? wcolr[(size_t)(k + P) * 64] : 0.0f;
+        }
+        if (k < n_old) step(k, cur.x, cur.y, curw, std::false_type{});
+      }
+    }
+  }
+  // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
+  if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
+    int smax = n_sp;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(smax, off, 64);
+      smax = o > smax ? o : smax;
+    }
+    smax = __builtin_amdgcn_readfirstlane(smax);
+    if (HET) {
+      // add_car :97-114 car by car: each queues behind the road's tail at the moment it is created - the tail's
+      // OWN length and minimum gap - and brings the row add_new_cars drew for it (:164); as in k_move_t
+      int lcq = ring_adv(p.ld, n_old, C);
+      float tx = d.tailx[id];
+      int ta = d.taila[id];
+      const int ej = d.entry_idx[e];
+      const uint8_t *rows = (d.spawn_arch && d.spawn_mode == TFX_SPAWN_COUNTS && ej >= 0)
+                                ? d.spawn_arch + (size_t)tidx * d.spawn_arch_stride +
+                                      ((size_t)env * d.n_entry + ej) * d.spawn_arch_S
+                                : nullptr;
+      for (int s = 0; s < smax; ++s)
+        if (s < n_sp) {
+          const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
+          const float start = (lcq != p.ld) ? (tx - s_arch[ta * ARCH_W + AR_L]) - s_arch[ta * ARCH_W + AR_S0] : INFINITY;
+          const float xs = (start < 0.0f) ? start : 0.0f;
+          step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack(tick, row), std::false_type{});
+          lcq = wrap1(lcq + 1, C);
+          tx = xs;
+          ta = row;
+        }
+    } else {
+      for (int s = 0; s < smax; ++s)
+        if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick, std::false_type{});
+    }
+  }
+  // ---- the road's last car through tick t+1 ----------------------------------------------------
+  if (TWO && two && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
+    if (pend) step(p.n_tot, 0.0f, 0.0f, 0.0f, std::true_type{});
+  }
+
+  // ---- phase W -------------------------------------------------------------------------------
+  if (run) {
+    const int n_tot = p.n_tot;
+    if (e < d.r) {
+      int *ob = d.obs + (size_t)env * d.obs_len;
+      if (n_tot > 0) {
+        if (!two) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
+        ob[d.r + e] = n_det;
+      }
+      if (AGENT) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;  // accumulates over the agent step
+      else if (!two) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
+      if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+    }
+    if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
+    d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
+                          n_tot | (HET ? last_a << 16 : 0));
+    if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
+    if (far || kpop > KP) d.env_flag[env] = tick + 1;
+    if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
+    return n_tot;
+  }
+  return 0;
+}
+
 template <bool TWO, bool AGENT = false, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
-  constexpr int P = TT_P;
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
-  if (HET) {
-    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
-    __syncthreads();
-  }
+  if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA - ((AGENT && only_risky == 2) ? 1 : 0);
-  const int C = d.C;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
 
-  if (AGENT && only_risky && *d.risk_any != tick) return;  // (k_edge / k_tail has moved every other env and the clock)
+  if (AGENT && only_risky && risk_any_word(d, tidx) != tick) return;  // (k_edge / k_tail has moved every other env and the clock)
 
   unsigned long long my_updates = 0;
 
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);  // a tile never straddles envs
-    if (AGENT && only_risky && d.env_risk[env] != tick) continue;
+    if (AGENT && only_risky && risk_word(d, env, tidx) != tick) continue;
     // this tile goes through two ticks (wave-uniform)
-    const bool two = TWO && !(AGENT && d.env_risk[env] == tick + 1);
+    const bool two = TWO && !(AGENT && risk_word(d, env, tidx) == tick + 1);
     // (a stamp left by an earlier run at the same tick number - the clock can be set back - is honoured all the
     // way: this pass takes the tile one tick at a time, k_edge skips it, and the restricted launch must come)
-    if (AGENT && TWO && !two && lane == 0) *d.risk_any = tick + 1;
-    const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
-    const bool valid = e_slot >= 0;
-    const int e = valid ? e_slot : 0;
-    const int id = env * d.R + e;
-    const bool run = valid && !(AGENT && env_frozen(d, env, tick));
-    const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
-    const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
-    const int n_old = run ? p.n_old : 0;
-    const int n_sp = run ? p.n_tot - p.n_old : 0;
-
-    float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane;  // written: row k of this road = col[k * 64]
-    const float2 *colr = col + (size_t)hb * 64;                 // read: the live rows start hb rows down
-    float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
-    float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;  // side words: same rows as col
-    float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
-
-    int kmax = n_old;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const int o = __shfl_xor(kmax, off, 64);
-      kmax = o > kmax ? o : kmax;
-    }
-    kmax = __builtin_amdgcn_readfirstlane(kmax);
-
-    float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
-    float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
-    float y1w = 0.0f;                                      // side word of car k-1
-    float y1l = 0.0f, y2l = 0.0f;                          // HET: lengths of cars k-1 and k-2
-    int last_a = 0;                                        // HET: table row of the last car processed (the road's tail)
-    int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
-    bool open = true, far = false;
-    bool pend = false, pend_int = false;  // car k-1 survived tick t and is still to be stored; it is not the new head
-    float2 *wp = col;  // where the next surviving car goes: one row further down per survivor
-    int kq1 = 0x7fffffff;  // tick t+1 tests x instead of v from this car on (index of tick t)
-    float tail_x = 0.0f, tail_z = 0.0f;
-    const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
-
-    auto ld2 = [&](const float2 *ptr) {
-      const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ptr));
-      return make_float2(t.x, t.y);
-    };
-    auto st2 = [&](float2 *ptr, float a, float b) {
-      f2v t;
-      t.x = a;
-      t.y = b;
-      __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(ptr));
-    };
-    // Car k of this lane's road through tick t, car k-1 through tick t+1.  `last` (a compile-time flag): only
-    // the second half, for the road's last car.
-    auto step = [&](int k, float x, float v, float sw, auto last) {
-      constexpr bool LAST = decltype(last)::value;
-      float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
-      // (one wave-wide test per row.  Round 3 measured the alternatives on this kernel: the speeds read from memory
-      // tested once per group of P rows, 0.772 ms per pass against 0.764; no test at all - results wrong - 0.734)
-      const bool bad = !HET && ((!LAST && !idm_fast_domain(v)) || (TWO && two && !idm_fast_domain(y1v)));
-      const bool off_domain = !HET && __builtin_amdgcn_ballot_w64(bad) != 0ull;
-      float my_l = d.car_l;
-      if (HET) {
-        if (!LAST) {
-          last_a = side_arch(sw);
-          const float *me = s_arch + last_a * ARCH_W;
-          idm_step_het(d, me, x, v, xprev, vprev, llv, xn, vn);
-          my_l = me[AR_L];
-        }
-        if (TWO) idm_step_het(d, s_arch + side_arch(y1w) * ARCH_W, y1x, y1v, y2x, y2v, y2l, zx, zv);
-      } else if (d.fastdiv && !off_domain) {
-        if (!LAST) idm_step_fast(d, x, v, xprev, vprev, llv, xn, vn);
-        if (TWO) idm_step_fast(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
-      } else {
-        if (!LAST) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
-        if (TWO) idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
-      }
-      if (TWO && two && pend) {  // car k-1: the new head keeps its tick-t state (k_edge moves it), the others are a tick ahead
-        st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
-        if (W) wcol[wp - col] = y1w;
-        wp += 64;
-        if (pend_int) {
-          const float wq1 = (k - 1 >= kq1) ? zx : zv;
-          n_wait1 += (wq1 < d.thresh) ? 1 : 0;
-          n_det1 += (zx > d.near_end) ? 1 : 0;
-          if (LAST) tail_z = zx;  // (the road's last car is flushed by the LAST call)
-        }
-      }
-      if (LAST) return;
-      xprev = x;
-      vprev = v;
-      llv = my_l;
-      const bool was_open = open;
-      const bool pop = open && (xn > d.length);  // the while loop of :123
-      open = pop;
-      if (pop) {
-        if (kpop < KP) {
-          ocol[(size_t)kpop * 64] = make_float2(xn, vn);
-          if (W) owcol[(size_t)kpop * 64] = sw;
-        } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
-          st2(&col[(size_t)k * 64], xn, vn);
-          if (W) wcol[(size_t)k * 64] = sw;
-          wp = col + (size_t)(k + 1) * 64;
-        }
-        far = far || ((xn - d.length) > d.length);
-        ++kpop;
-      } else if (TWO && two) {
-        pend = true;
-        pend_int = !was_open;
-        if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
-      } else {
-        st2(wp, xn, vn);
-        if (W) wcol[wp - col] = sw;
-        wp += 64;
-      }
-      const float wq = (k >= kq) ? xn : vn;
-      n_wait += (wq < d.thresh) ? 1 : 0;
-      n_det += (xn > d.near_end) ? 1 : 0;
-      if (!TWO) tail_x = xn;  // (a pair: y1 holds the last car's new state when the walk ends)
-      y2x = y1x;
-      y2v = y1v;
-      y1x = xn;
-      y1v = vn;
-      if (W) y1w = sw;
-      if (HET) {
-        y2l = y1l;
-        y1l = my_l;
-      }
-    };
-
-    // ---- cars in memory: rows 0 .. kmax-1 of the live part, P rows in flight --------------------
-    float2 pf[P];
-    float pfw[P];
-    const float *wcolr = wcol + (size_t)hb * 64;
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      pf[u] = (u < n_old) ? ld2(&colr[(size_t)u * 64]) : make_float2(0.0f, 0.0f);
-      pfw[u] = (W && u < n_old) ? wcolr[(size_t)u * 64] : 0.0f;
-    }
-    for (int k0 = 0; k0 < kmax; k0 += P) {
-#pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int k = k0 + u;
-        if (k < kmax) {
-          const float2 cur = pf[u];
-          const float curw = pfw[u];
-          if (k + P < kmax) {
-            pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
-            pfw[u] = (W && k + P < n_old) ? wcolr[(size_t)(k + P) * 64] : 0.0f;
-          }
-          if (k < n_old) step(k, cur.x, cur.y, curw, std::false_type{});
-        }
-      }
-    }
-    // ---- cars spawned this tick (add_car :97-114): they queue behind the tail ------------------
-    if (__builtin_amdgcn_ballot_w64(n_sp > 0) != 0ull) {
-      int smax = n_sp;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(smax, off, 64);
-        smax = o > smax ? o : smax;
-      }
-      smax = __builtin_amdgcn_readfirstlane(smax);
-      if (HET) {
-        // add_car :97-114 car by car: each queues behind the road's tail at the moment it is created - the tail's
-        // OWN length and minimum gap - and brings the row add_new_cars drew for it (:164); as in k_move_t
-        int lcq = ring_adv(p.ld, n_old, C);
-        float tx = d.tailx[id];
-        int ta = d.taila[id];
-        const int ej = d.entry_idx[e];
-        const uint8_t *rows = (d.spawn_arch && d.spawn_mode == TFX_SPAWN_COUNTS && ej >= 0)
-                                  ? d.spawn_arch + (size_t)tidx * d.spawn_arch_stride +
-                                        ((size_t)env * d.n_entry + ej) * d.spawn_arch_S
-                                  : nullptr;
-        for (int s = 0; s < smax; ++s)
-          if (s < n_sp) {
-            const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
-            const float start = (lcq != p.ld) ? (tx - s_arch[ta * ARCH_W + AR_L]) - s_arch[ta * ARCH_W + AR_S0] : INFINITY;
-            const float xs = (start < 0.0f) ? start : 0.0f;
-            step(n_old + s, xs, s_arch[row * ARCH_W + AR_V], side_pack((float)tick, row), std::false_type{});
-            lcq = wrap1(lcq + 1, C);
-            tx = xs;
-            ta = row;
-          }
-      } else {
-        for (int s = 0; s < smax; ++s)
-          if (s < n_sp) step(n_old + s, spawned_x(d, p.xs0, s), d.car_v, (float)tick, std::false_type{});
-      }
-    }
-    // ---- the road's last car through tick t+1 ----------------------------------------------------
-    if (TWO && two && __builtin_amdgcn_ballot_w64(pend) != 0ull) {
-      if (pend) step(p.n_tot, 0.0f, 0.0f, 0.0f, std::true_type{});
-    }
-
-    // ---- phase W -------------------------------------------------------------------------------
-    if (run) {
-      const int n_tot = p.n_tot;
-      if (e < d.r) {
-        int *ob = d.obs + (size_t)env * d.obs_len;
-        if (n_tot > 0) {
-          if (!two) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
-          ob[d.r + e] = n_det;
-        }
-        if (AGENT) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;  // accumulates over the agent step
-        else if (!two) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
-        if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
-      }
-      if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
-      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
-                            n_tot | (HET ? last_a << 16 : 0));
-      if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
-      if (far || kpop > KP) d.env_flag[env] = tick + 1;
-      if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
-      my_updates += (unsigned long long)n_tot;
-    }
+    if (AGENT && TWO && !two && lane == 0) risk_any_word(d, tidx) = tick + 1;
+    my_updates += (unsigned long long)move_tt_tile<TWO, AGENT, W, HET>(d, tile, env, lane, tick, tick_sp, tidx, two, s_arch);
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
@@ -313,48 +321,56 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
   if (blockIdx.x == 0 && threadIdx.x == 0) *d.tickB = tick;
 }
 
-// Before a pair inside an agent step: marks the envs in which the pair's first tick could overflow a ring or
-// pop / hand over more cars than the pair's bookkeeping assumes (see the head of this file).
+// Could the tick starting at `tick` overflow a ring of this lane's road - or pop / hand over more cars than a pair's
+// bookkeeping assumes (see the head of this file)?  A bound, not the IDM result: a car moves at most
+// rate * v + a rate^2 / 2 per tick because the IDM acceleration never exceeds a (:56-57: a * (1 - q^delta - u^2) with
+// q >= 0; heterogeneous cars: the table's largest a).  Reads the ring words through `d` (k_tail: its LDS copies) and the
+// road's first cars from the rows as they stand (after a pair: already at `tick`).
+__device__ __forceinline__ bool risk_lane(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx) {
+  const int C = d.C;
+  const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
+  if (e < 0) return false;
+  const float half_ar2 = (0.5f * (d.risk_a * d.rate)) * d.rate;
+  const int id = env * d.R + e;
+  const int n = ring_count(d.leading[id], d.lastcar[id], C);
+  const int ej = d.entry_idx[e];
+  const int c_sp = ej >= 0 ? spawn_count(d, env, e, ej, tick_sp, tidx) : 0;
+  bool risky = n + c_sp > C - 2;
+  // how many cars could leave: a prefix of the cars that can reach the end of the road at all
+  const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)rec_hb(d.rec[id].y) * 64;
+  int pops = 0;
+  for (int j = 0; j <= KP && j < n; ++j) {
+    const float2 c = col[(size_t)j * 64];
+    const float reach = c.x + __builtin_fmaxf(d.rate * c.y + half_ar2, 0.0f);
+    if (!(reach > d.length)) break;
+    ++pops;
+    if ((reach - d.length) > d.length) risky = true;  // could run through the next road as well
+  }
+  if (pops > KP) risky = true;
+  const int nx = d.nexts[e];
+  if (pops > 0 && nx >= 0) {
+    const int idn = env * d.R + nx;
+    if (ring_count(d.leading[idn], d.lastcar[idn], C) + pops > C - 2) risky = true;
+  }
+  return risky;
+}
+
+// Before a pair inside an agent step: marks the envs in which the pair's first tick could overflow (risk_lane).  Only
+// the FIRST pair of a decision needs this launch: k_tail<AGENT> evaluates the same bound for the pair that follows it
+// as its last phase (tfx_tail.hpp).
 __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;
-  const int C = d.C;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-  // the farthest a car can move in a tick beyond rate * v: the IDM acceleration is at most a (:56-57: a * (1 - q^delta - u^2)
-  // with q >= 0), for heterogeneous cars at most the table's largest a
-  const float half_ar2 = (0.5f * (d.risk_a * d.rate)) * d.rate;
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);
     if (env_frozen(d, env, tick)) continue;
-    const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
-    if (e < 0) continue;
-    const int id = env * d.R + e;
-    const int n = ring_count(d.leading[id], d.lastcar[id], C);
-    const int ej = d.entry_idx[e];
-    const int c_sp = ej >= 0 ? spawn_count(d, env, e, ej, tick_sp, tidx) : 0;
-    bool risky = n + c_sp > C - 2;
-    // how many cars could leave: a prefix of the cars that can reach the end of the road at all
-    const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)rec_hb(d.rec[id].y) * 64;
-    int pops = 0;
-    for (int j = 0; j <= KP && j < n; ++j) {
-      const float2 c = col[(size_t)j * 64];
-      const float reach = c.x + __builtin_fmaxf(d.rate * c.y + half_ar2, 0.0f);
-      if (!(reach > d.length)) break;
-      ++pops;
-      if ((reach - d.length) > d.length) risky = true;  // could run through the next road as well
-    }
-    if (pops > KP) risky = true;
-    const int nx = d.nexts[e];
-    if (pops > 0 && nx >= 0) {
-      const int idn = env * d.R + nx;
-      if (ring_count(d.leading[idn], d.lastcar[idn], C) + pops > C - 2) risky = true;
-    }
-    if (risky) {
-      d.env_risk[env] = tick + 1;
-      *d.risk_any = tick + 1;
+    if (risk_lane(d, tile, env, lane, tick, tick_sp, tidx)) {
+      risk_word(d, env, tidx) = tick + 1;
+      risk_any_word(d, tidx) = tick + 1;
     }
   }
 }
@@ -370,7 +386,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   const int C = d.C;
   // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
   // one-tick launch of their own)
-  if (AGENT && (d.env_risk[env] == tick || env_frozen(d, env, tick))) return 0;
+  if (AGENT && ((!d.no_stamps && risk_word(d, env, tidx) == tick) || env_frozen(d, env, tick))) return 0;
   const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
   if (e < 0) return 0;
   const int id = env * d.R + e;
@@ -469,7 +485,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
         const int row = (rows && s < d.spawn_arch_S) ? (rows[s] & (TFX_MAX_ARCH - 1)) : 0;
         const float start = (lcq != p.ld) ? (tx - arch[ta * ARCH_W + AR_L]) - arch[ta * ARCH_W + AR_S0] : INFINITY;
         const float xs = (start < 0.0f) ? start : 0.0f;
-        car(n_old + s, xs, arch[row * ARCH_W + AR_V], true, side_pack((float)tick, row));
+        car(n_old + s, xs, arch[row * ARCH_W + AR_V], true, side_pack(tick, row));
         lcq = wrap1(lcq + 1, C);
         tx = xs;
         ta = row;
@@ -497,10 +513,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
 template <bool AGENT, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) void k_edge(const Dev d, const int tidx) {
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
-  if (HET) {
-    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
-    __syncthreads();
-  }
+  if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tick = *d.tickA;

@@ -228,23 +228,35 @@ void k_res(const Dev d, const ResArgs a) {
             while (k < a.ps.n_cdf - 1 && u[0] >= a.ps.cdf[k]) ++k;
             return k;
           };
-          if (gap < 0) gap = gap_of(0u);
-          if (gap > 0) {
-            --gap;
-          } else {
-            for (int guard = 0; guard < 1024; ++guard) {
-              const unsigned c = c0 + (unsigned)lane;
-              const int g = gap_of(2u + 2u * c);
-              const unsigned long long stop = __builtin_amdgcn_ballot_w64(g > 0);
-              const int f = stop ? __builtin_ctzll(stop) : 63;
-              if (lane <= f) {
-                philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, a.ps.seed_lo, a.ps.seed_hi, u);
+          if (a.ps.regular) {  // the `regular` generator, as k_poisson runs it
+            const bool due = a.ps.every == 0 || gap % a.ps.every == 0;
+            ++gap;
+            if (due) {
+              for (int j = lane; j < a.ps.burst; j += 64) {
+                philox4x32(1u + 2u * (c0 + (unsigned)j), gid, 0x524F4144u, 0u, a.ps.seed_lo, a.ps.seed_hi, u);
                 atomicAdd(&hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
               }
-              c0 += (unsigned)(f + 1);
-              if (stop) {
-                gap = __shfl(g, f, 64) - 1;
-                break;
+              c0 += (unsigned)a.ps.burst;
+            }
+          } else {
+            if (gap < 0) gap = gap_of(0u);
+            if (gap > 0) {
+              --gap;
+            } else {
+              for (int guard = 0; guard < 1024; ++guard) {
+                const unsigned c = c0 + (unsigned)lane;
+                const int g = gap_of(2u + 2u * c);
+                const unsigned long long stop = __builtin_amdgcn_ballot_w64(g > 0);
+                const int f = stop ? __builtin_ctzll(stop) : 63;
+                if (lane <= f) {
+                  philox4x32(1u + 2u * c, gid, 0x524F4144u, 0u, a.ps.seed_lo, a.ps.seed_hi, u);
+                  atomicAdd(&hist[(int)(((unsigned long long)u[0] * (unsigned)d.n_entry) >> 32)], 1);
+                }
+                c0 += (unsigned)(f + 1);
+                if (stop) {
+                  gap = __shfl(g, f, 64) - 1;
+                  break;
+                }
               }
             }
           }

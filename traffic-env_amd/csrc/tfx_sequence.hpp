@@ -32,21 +32,57 @@ int ensure_split(tfx_handle h, hipStream_t caller) {
   return TFX_OK;
 }
 
+// Whatever a launch sequence changes in the handle while it enqueues - the device block (agent mode, reward
+// accumulation, the sub-range of one half), the half being enqueued - is put back on EVERY exit, and a second stream
+// that was forked is joined back into the caller's stream, so that work already enqueued there stays ordered before
+// whatever the caller enqueues next: an error in the middle of a sequence leaves a handle the next call can use.
+struct SeqGuard {
+  tfx_handle h;
+  Dev keep;
+  hipStream_t user = nullptr;
+  bool forked = false;
+  explicit SeqGuard(tfx_handle hh) : h(hh), keep(hh->d) {}
+  int fork(hipStream_t st) {
+    user = st;
+    HIPCHK(hipEventRecord(h->split_fork, st));
+    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    forked = true;
+    return TFX_OK;
+  }
+  int join() {
+    if (!forked) return TFX_OK;
+    forked = false;
+    HIPCHK(hipEventRecord(h->split_join, h->split_stream));
+    HIPCHK(hipStreamWaitEvent(user, h->split_join, 0));
+    return TFX_OK;
+  }
+  ~SeqGuard() {
+    h->d = keep;
+    h->split_half = -1;
+    h->split_first = false;
+    h->size_only = false;
+    if (forked) {  // (an error exit: best effort, the error being reported is the first one)
+      const std::string first = g_err;
+      (void)join();
+      g_err = first;
+    }
+  }
+};
+
 // the launches of one agent step, in order, on `st`
 // split: the ticks run as two halves of the env range, the second on the handle's own stream (as step_chunk does for
 // tfx_step; launched eagerly - a batch big enough to split is not bound by its launches)
 int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
-                   hipStream_t st, long long &n_fused, long long &n_pair, bool split = false) {
+                   hipStream_t st, long long &n_fused, long long &n_pair, long long &n_env, bool split = false,
+                   bool envk = false) {
   Dev &d = h->d;
-  n_fused = n_pair = 0;
-  const int keep_mode = d.agent_mode, keep_acc = d.accum_rewards;
+  n_fused = n_pair = n_env = 0;
+  SeqGuard guard(h);
   if (res_usable(h, n_ticks)) {
     // every tick of the decision AND its tail (remi, observation, rewards, done flags) in one launch
     d.agent_mode = 1;
     d.accum_rewards = remi ? 0 : 1;
     const int rc = launch_res(h, n_ticks, st, 1, remi, aobs, areward, adone);
-    d.agent_mode = keep_mode;
-    d.accum_rewards = keep_acc;
     if (rc == TFX_OK) n_fused = n_ticks;
     return rc;
   }
@@ -57,7 +93,15 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
   const Dev whole = h->d;
-  if (split) {
+  if (envk) {
+    // the whole decision in one launch, a workgroup per env (tfx_env.hpp): the bound k_risk takes is evaluated inside,
+    // an env that overflows stops on the spot
+    rc = launch_env(h, n_ticks, st, true);
+    if (rc != TFX_OK) return rc;
+    n_pair = 2 * (n_ticks / 2);
+    n_env = n_ticks;
+  }
+  if (split && !envk) {
     h->size_only = true;  // (grids are sized for the whole range)
     (void)launch_move_tt<true, true>(h, 0, nullptr);
     (void)launch_move_tt<false, true>(h, 0, nullptr);
@@ -70,11 +114,10 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     // start than a small batch's whole pair)
     hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, st, whole.tickA, whole.tickB, h->tick2);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(h->split_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    if (int frc = guard.fork(st)) return frc;
   }
   hipStream_t user_st = st;
-  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
+  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK && !envk; ++half) {
     if (split) {
       const int n0 = whole.E / 2;
       h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
@@ -89,11 +132,13 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
       // tick at a time (k_risk)
       for (; t + 1 < n_ticks && rc == TFX_OK; t += 2) {
         rc = launch_inputs(h, st);
-        if (rc == TFX_OK) rc = launch_risk(h, t, st);
+        // (k_tail evaluates the bound for the pair that follows it: only the first pair pays a launch of its own)
+        const bool tail = tail_usable(h);
+        if (rc == TFX_OK && !(tail && t > 0)) rc = launch_risk(h, t, st);
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
-        if (rc == TFX_OK && tail_usable(h)) {
+        if (rc == TFX_OK && tail) {
           // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
-          rc = launch_tail(h, t, st, true);
+          rc = launch_tail(h, t, st, true, t + 3 < n_ticks ? 1 : 0);
           if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 2);
           if (rc == TFX_OK) rc = launch_advance(h, t + 1, st, 1);
         } else {
@@ -115,16 +160,13 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   }
   h->split_half = -1;
   st = user_st;
-  if (split) {
-    n_pair /= 2;  // (both halves counted them)
-    if (rc == TFX_OK) {
-      HIPCHK(hipEventRecord(h->split_join, h->split_stream));
-      HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
-    }
-  }
-  d.agent_mode = keep_mode;
-  d.accum_rewards = keep_acc;
   if (rc != TFX_OK) return rc;
+  if (split && !envk) {
+    n_pair /= 2;  // (both halves counted them)
+    if (int jrc = guard.join()) return jrc;
+  }
+  d.agent_mode = guard.keep.agent_mode;  // the tail kernels below run outside the step's tick loop
+  d.accum_rewards = guard.keep.accum_rewards;
   if (remi) {
     hipLaunchKernelGGL(k_remi, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d);
     HIPCHK(hipGetLastError());
@@ -195,6 +237,22 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
 
 // n_ticks ticks on the per-tick kernels, the env range in two halves on two streams where that pays
 int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
+  if (env_usable(h, n_ticks)) {
+    // all the ticks in ONE launch, a workgroup per env (tfx_env.hpp)
+    const bool timed = h->prof && h->ev_used < h->ev_ticks;
+    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
+    if (timed) HIPCHK(hipEventRecord(e[0], st));
+    if (int rc = launch_env(h, n_ticks, st)) return rc;
+    if (timed) {
+      HIPCHK(hipEventRecord(e[1], st));
+      HIPCHK(hipEventRecord(e[2], st));
+      h->ev_weight[h->ev_used] = n_ticks;
+      ++h->ev_used;
+    }
+    h->env_ticks += n_ticks;
+    h->pair_ticks += 2 * (n_ticks / 2);
+    return TFX_OK;
+  }
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
     if (int rc = ensure_split(h, st)) return rc;
@@ -206,14 +264,15 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
       (void)launch_advance(h, 0, nullptr);
       h->size_only = false;
     }
+    SeqGuard guard(h);
     const Dev whole = h->d;
     const int n0 = whole.E / 2;
     const long long pair0 = h->pair_ticks, tail0 = h->tail_ticks;
     // (the clock copy runs on the caller's stream, ahead of the fork: see agent_sequence)
     hipLaunchKernelGGL(k_clock_copy, dim3(1), dim3(1), 0, st, whole.tickA, whole.tickB, h->tick2);
-    int rc = hipGetLastError() == hipSuccess ? TFX_OK : fail(TFX_EDEVICE, "k_clock_copy launch failed");
-    HIPCHK(hipEventRecord(h->split_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+    HIPCHK(hipGetLastError());
+    if (int frc = guard.fork(st)) return frc;
+    int rc = TFX_OK;
     for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
       h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
       h->split_half = half;
@@ -222,13 +281,11 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
       h->d = whole;
     }
     h->split_half = -1;
-    if (rc != TFX_OK) return rc;
     h->pair_ticks = pair0 + (h->pair_ticks - pair0) / 2;  // (both halves counted them)
     h->tail_ticks = tail0 + (h->tail_ticks - tail0) / 2;
+    if (rc != TFX_OK) return rc;  // (the guard joins the second stream)
     h->split_ticks += n_ticks;
-    HIPCHK(hipEventRecord(h->split_join, h->split_stream));
-    HIPCHK(hipStreamWaitEvent(st, h->split_join, 0));
-    return TFX_OK;
+    return guard.join();
   }
   return step_range(h, n_ticks, st);
 }

@@ -5,14 +5,22 @@
 // 156 MB, 157 us of a 937 us pair).  All three only ever touch ONE env's words at a time - the handoff goes from a
 // road to its successor in the same env (advance_finished_cars, traffic_env.py:117-135), the lights and the tails
 // update_lights reads (:81-94) are the env's own - so a workgroup that owns an env can run the three back to back
-// with workgroup barriers between them: the dependencies that forced three launches are inside the workgroup, and
-// what k_edge writes for k_advance(t+1) (and k_advance(t) for k_edge) is found again in the L2 it was just
-// written to.  One launch instead of three, and about half the HBM traffic.
+// with workgroup barriers between them: the dependencies that forced three launches are inside the workgroup.
+//
+// Round 4: the env's ring words live in LDS for the whole launch.  Round 3's k_tail was pure latency (PMC: 83 %
+// of its wave-cycles waiting, 6 % VALU): every phase walked chains of three or four dependent global loads
+// (leading -> rec -> pred -> rec[pred] -> outbox ...) through an L2 the other half's car pass keeps busy.  Now one
+// coalesced burst brings leading | lastcar | rec | tailx | the light words (28 B per road + 8 B per intersection: 32 KB
+// at cfg2) into LDS, the three phases - and, inside agent steps, k_risk's bound for the NEXT pair - run on the LDS copies
+// through a device block whose pointers are shifted onto them (the phase code is the same as k_advance's and k_edge's),
+// and one burst writes them back.  What still goes to memory per phase is one level: the head car and the pass's second
+// record (rec2) for the edge work, the outbox rows of roads that popped.  Envs too big for a workgroup's LDS (cfg4: 16 640
+// roads) take the three launches instead (tail_usable).
 //
 // Ordering inside the workgroup: every phase reads words other lanes of the SAME workgroup wrote in the phase
-// before (ring indices, tails, road records, outbox rows, light words).  __syncthreads() is a workgroup-scope
-// release / acquire; all wavefronts of a workgroup share their CU's vector L1, so nothing more is needed (no word
-// crosses a workgroup, hence no agent-scope fence - the cost that sank round 2's cross-workgroup fusion).
+// before (ring indices, tails, road records: LDS; outbox rows, cars handed over: global).  __syncthreads() is a
+// workgroup-scope release / acquire; all wavefronts of a workgroup share their CU's vector L1, so nothing more is needed
+// (no word crosses a workgroup, hence no agent-scope fence - the cost that sank round 2's cross-workgroup fusion).
 //
 // Clock: the pass left tick t in tickB; this kernel leaves t + 2 in tickA for the next move kernel (nobody reads
 // tickA inside this launch, and tickB is not written, so workgroups that start late read the same t).
@@ -23,37 +31,108 @@
 
 namespace tfx {
 
+// bytes of LDS the staged form needs for one env
+inline size_t tail_lds_bytes(int R, int I, bool het) {
+  return (size_t)R * (sizeof(int4) + 3 * sizeof(int) + (het ? sizeof(int) : 0)) + (size_t)2 * I * sizeof(int);
+}
+
 // AGENT: inside an agent step (tfx_agent_step).  Envs that stand still are skipped by the phases themselves; envs k_risk
 // marked for this pair (env_risk == t + 1: their first tick could overflow, so the pass took them through ONE tick) get
 // the advance of tick t here and their whole second tick from the two restricted launches that follow
-// (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).
+// (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).  risk_next != 0: another pair follows in
+// the same decision - the last phase evaluates k_risk's bound for it (the state it needs is what advance(t + 1) has
+// just left in LDS), so only the first pair of a decision pays a k_risk launch.
 // W: validate mode - the cars' side words travel along (edge_tile)
 // HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
 // from an LDS copy of the table
 template <bool GREEDY = false, bool AGENT = false, bool W = false, bool HET = false>
-__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx) {
+__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const int risk_next) {
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
+  extern __shared__ int4 s_dyn[];  // rec[R] | leading[R] | lastcar[R] | tailx[R] | (HET: taila[R]) | lights[2 I]
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
-  if (HET) {
-    if (threadIdx.x < TFX_MAX_ARCH * ARCH_W) s_arch[threadIdx.x] = d.arch_tab[threadIdx.x];
-    __syncthreads();
-  }
+  if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwv = blockDim.x >> 6;
   const int tick = *d.tickB;  // first tick of the pair
   const int per_env = d.I + (d.R - d.r);
   const int sp0 = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? (tick + 1) % d.spawn_period : 0;
+  const int R = d.R;
+  int4 *const s_rec = s_dyn;
+  int *const s_ld = reinterpret_cast<int *>(s_rec + R);
+  int *const s_lc = s_ld + R;
+  float *const s_tx = reinterpret_cast<float *>(s_lc + R);
+  int *const s_ta = reinterpret_cast<int *>(s_tx + R);
+  int *const s_lt = s_ta + (HET ? R : 0);
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(d, env, s, tick, tidx);
-    if (AGENT && d.env_risk[env] == tick + 1) continue;  // (workgroup-uniform; nobody waits at a barrier for it)
-    __syncthreads();
-    for (int g = wv; g < d.G; g += nwv)
-      my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(d, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch);
-    __syncthreads();
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(d, env, s, tick + 1, tidx + 1);
+    Dev dl = d;
+    const size_t base = (size_t)env * R;
+    {
+      for (int e = threadIdx.x; e < R; e += blockDim.x) {
+        s_rec[e] = d.rec[base + e];
+        s_ld[e] = d.leading[base + e];
+        s_lc[e] = d.lastcar[base + e];
+        s_tx[e] = d.tailx[base + e];
+        if (HET) s_ta[e] = d.taila[base + e];
+      }
+      const int *lt = d.lights + (size_t)env * d.lights_stride;
+      for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) s_lt[i] = lt[i];
+      // the phase code indexes its arrays with env * R + e: pointers that land on the LDS copies for THIS env
+      dl.rec = s_rec - base;
+      dl.leading = s_ld - base;
+      dl.lastcar = s_lc - base;
+      dl.tailx = s_tx - base;
+      if (HET) dl.taila = s_ta - base;
+      dl.lights = s_lt;
+      dl.lights_stride = 0;
+      __syncthreads();
+    }
+    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick, tidx);
+    // (workgroup-uniform: the envs k_risk sorted out get their second tick from the launches behind this one)
+    const bool sorted_out = AGENT && risk_word(d, env, tidx) == tick + 1;
+    if (sorted_out) {
+      // their second tick is still to come (the launches behind this one): no bound can be taken yet, so they take
+      // the next pair one tick at a time as well
+      if (risk_next && threadIdx.x == 0) {
+        risk_word(d, env, tidx + 2) = tick + 3;
+        risk_any_word(d, tidx + 2) = tick + 3;
+      }
+    } else {
+      __syncthreads();
+      for (int g = wv; g < d.G; g += nwv)
+        my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(dl, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch);
+      __syncthreads();
+      for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick + 1, tidx + 1);
+      if (AGENT && risk_next) {
+        __syncthreads();
+        const int t2 = tick + 2;
+        if (!env_frozen(d, env, t2)) {
+          const int sp2 = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? t2 % d.spawn_period : 0;
+          bool risky = false;
+          for (int g = wv; g < d.G; g += nwv) risky = risk_lane(dl, (long)env * d.G + g, env, lane, t2, sp2, tidx + 2) || risky;
+          if (__builtin_amdgcn_ballot_w64(risky) != 0ull && lane == 0) {
+            risk_word(d, env, tidx + 2) = t2 + 1;
+            risk_any_word(d, tidx + 2) = t2 + 1;
+          }
+        }
+      }
+    }
+    {
+      __syncthreads();
+      for (int e = threadIdx.x; e < R; e += blockDim.x) {
+        d.rec[base + e] = s_rec[e];
+        d.leading[base + e] = s_ld[e];
+        d.lastcar[base + e] = s_lc[e];
+        d.tailx[base + e] = s_tx[e];
+        if (HET) d.taila[base + e] = s_ta[e];
+        for (int k = 0; k < d.exp_pad_n; ++k) d.exp_pad[(size_t)k * d.E * R + base + e] = s_rec[e];
+      }
+      int *lt = d.lights + (size_t)env * d.lights_stride;
+      for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) lt[i] = s_lt[i];
+      __syncthreads();  // (the next env's loads overwrite the copies)
+    }
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);

@@ -6,10 +6,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFX_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libtfx_hip.so"))
 
-MAX_ARCH = 8
+MAX_ARCH = 64
 ACTION_BUFFER, ACTION_BROADCAST, ACTION_CYCLE, ACTION_GREEDY = 0, 1, 2, 3
 SPAWN_NONE, SPAWN_COUNTS, SPAWN_PERIODIC = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class TfxConfig(C.Structure):
@@ -22,7 +22,7 @@ class TfxConfig(C.Structure):
                 ("overflow_penalty", C.c_float), ("eps", C.c_float),
                 ("learn_switch", C.c_int32), ("validate", C.c_int32), ("entry_spec", C.c_uint32),
                 ("env_id_offset", C.c_int32), ("layout", C.c_int32),
-                ("n_archetypes", C.c_int32), ("arch", (C.c_float * 8) * 8)]
+                ("n_archetypes", C.c_int32), ("arch", (C.c_float * 8) * MAX_ARCH)]
 
 
 class TfxBuffers(C.Structure):
@@ -52,6 +52,7 @@ _PROTOS = {
     "tfx_set_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_spawns": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_set_poisson": (C.c_int, [C.c_void_p, C.c_double, C.c_uint64, C.c_void_p, C.c_int32]),
+    "tfx_set_regular": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64]),
     "tfx_set_spawn_archetypes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "tfx_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "tfx_move_cars": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -76,8 +77,10 @@ _PROTOS = {
     "tfx_fused_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tfx_pair_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_tail_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tfx_env_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_split_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_step_kernel": (C.c_char_p, [C.c_void_p]),
+    "tfx_debug_fail_after": (C.c_int, [C.c_void_p, C.c_int32]),
 }
 
 

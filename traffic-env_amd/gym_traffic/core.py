@@ -330,6 +330,15 @@ class TfxEngine(object):
                                            cdf.ctypes.data_as(C.c_void_p), int(cdf.size)))
         self._spawn_bound = None
 
+    def set_regular(self, cars_per_tick, seed=0):
+        """On-device form of the reference's `regular` generator (traffic_env.py:167-176): ceil(cars_per_tick) cars
+        every round(1 / cars_per_tick) ticks (Python's round, as the reference computes it), each on an entry road drawn
+        from the env's Philox stream; cars_per_tick = cars_per_sec * rate for the whole env."""
+        import math
+        every, burst = round(1 / cars_per_tick), math.ceil(cars_per_tick)
+        nat.check(self.lib.tfx_set_regular(self.h, int(every), int(burst), int(seed)))
+        self._spawn_bound = None
+
     def set_greedy(self, spacing=3):
         """On-device greedy controller (algorithms/greedy.py:14-16), a decision every `spacing` ticks."""
         key = ("greedy", int(spacing))
@@ -584,6 +593,12 @@ class TfxEngine(object):
         """Ticks of those whose pair was finished by ONE launch, a workgroup per env (k_tail; tfx_tail_ticks)."""
         n = C.c_int64()
         nat.check(self.lib.tfx_tail_ticks(self.h, C.byref(n)))
+        return int(n.value)
+
+    def env_ticks(self):
+        """Ticks run so far by k_env: one launch per call, a workgroup per env, ring words resident in LDS (tfx_env_ticks)."""
+        n = C.c_int64()
+        nat.check(self.lib.tfx_env_ticks(self.h, C.byref(n)))
         return int(n.value)
 
     def split_ticks(self):

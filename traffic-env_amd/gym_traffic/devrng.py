@@ -106,3 +106,33 @@ class PoissonMirror(object):
                     self.gap[e] = int(gaps[f]) - 1
                     break
         return out
+
+
+class RegularMirror(object):
+    """Host mirror of the on-device `regular` generator (tfx_set_regular; the reference's traffic_env.py:167-176):
+    `burst` = ceil(cars_per_tick) cars in every tick i of an env's generator with i % every == 0, every =
+    round(1 / cars_per_tick); car c of env e (counted over the env's whole stream) enters on entry index
+    floor(u * n_entry / 2^32) with u the first word of draw 1 + 2c of the env's Philox stream."""
+
+    def __init__(self, cars_per_tick, seed, n_entry, env_ids):
+        self.every, self.burst = round(1 / cars_per_tick), math.ceil(cars_per_tick)
+        self.k0, self.k1 = int(seed) & MASK, (int(seed) >> 32) & MASK
+        self.n_entry = int(n_entry)
+        self.env_ids = [int(e) for e in env_ids]
+        self.i = {e: 0 for e in self.env_ids}
+        self.car = {e: 0 for e in self.env_ids}
+
+    def next_tick(self, frozen=()):
+        """int32 [len(env_ids), n_entry] cars per entry road this tick (entry index order)."""
+        out = np.zeros((len(self.env_ids), self.n_entry), np.int32)
+        for row, e in enumerate(self.env_ids):
+            if e in frozen:
+                continue
+            due = self.every == 0 or self.i[e] % self.every == 0
+            self.i[e] += 1
+            if due:
+                c = self.car[e] + np.arange(self.burst, dtype=np.uint64)
+                ur = philox4x32_first(np.uint64(1) + np.uint64(2) * c, e, TAG_ROAD, 0, self.k0, self.k1)
+                np.add.at(out[row], ((ur * np.uint64(self.n_entry)) >> np.uint64(32)).astype(np.int64), 1)
+                self.car[e] += self.burst
+        return out

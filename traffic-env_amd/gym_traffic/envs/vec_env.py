@@ -6,7 +6,8 @@ round trip inside `step`.  Spawns come either from per-env replicas of the refer
 generators (`spawn='poisson'|'regular'`: host RandomState schedules, bit-identical per env to a
 reference env seeded `seed + env_id`), from the on-device form of the reference's Poisson generator
 (`spawn='device'`: Philox streams keyed by (seed, global env id), no host work per tick - the one to
-use for throughput) or from the on-device fixed-rate rule (`spawn='periodic'`).
+use for throughput), from the on-device form of its `regular` generator (`spawn='regular_device'`: the reference's car
+counts per tick, entry roads from the same Philox streams) or from the on-device fixed-rate rule (`spawn='periodic'`).
 Sharding across GPUs is by env id (gym_traffic/distributed.py); envs share nothing.
 """
 import numpy as np
@@ -42,12 +43,14 @@ class TrafficVecEnv(object):
                                             max(1, eng.n_entry), self.cars_per_sec * self.rate)
         elif spawn == 'device':
             eng.set_poisson(self.cars_per_sec * self.rate, seed=seed)
+        elif spawn == 'regular_device':
+            eng.set_regular(self.cars_per_sec * self.rate, seed=seed)
         elif spawn == 'periodic':
             eng.set_spawns(period=spawn_period)
         elif spawn in (None, 'none'):
             eng.set_spawns()
         else:
-            raise ValueError("spawn must be poisson|regular|device|periodic|none")
+            raise ValueError("spawn must be poisson|regular|device|regular_device|periodic|none")
         self._phase_rng = np.random.RandomState(seed + 7919 + self.env_id_offset)
         self.obs, self.rewards, self.done = eng.obs, eng.rewards, eng.done
 
@@ -105,6 +108,36 @@ class TrafficVecEnv(object):
 
     def remi_reward(self):
         return self.engine.remi_reward()
+
+    # ---- validate-mode metrics, batched (reference: traffic_test.py:41-46, traffic_env.py:139-157, util.py:91-92) ----
+    def light_times(self, actions):
+        """float32 [E, I]: for every light the action flips, the seconds it had been in its phase -
+        (elapsed + 1) * xor(current_phase, action) / 2, what the Repeater reports per decision as
+        info['light_times'] in validate mode (traffic_test.py:41-46); 0 where the action flips nothing.  Call it
+        BEFORE the decision's step, like the reference does.  The single-env list is `t[k][t[k] != 0]`."""
+        eng = self.engine
+        a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+        a = a.to(eng.device)
+        flips = (eng.current_phase != 0) != (a != 0)
+        return ((eng.elapsed + 1) * flips).to(torch.float32) / 2
+
+    def unfinished(self):
+        """int64 [E]: cars still on the train roads, `np.sum(env.cars_on_roads())` per env (util.py:92)."""
+        eng = self.engine
+        return eng.cars_on_roads_flat()[:, :eng.r].sum(dim=1)
+
+    def trip_times(self, env=None):
+        """Trip times (seconds) of the cars that left the map since the last reset, in the order advance_hack logs
+        them (traffic_env.py:153-154): a list of float32 arrays, one per env - or env `env`'s array.  Needs
+        validate=True."""
+        eng = self.engine
+        if eng.n_trips is None:
+            raise RuntimeError("trip times are recorded in validate mode only (TrafficVecEnv(..., validate=True))")
+        n = eng.n_trips.cpu().numpy()
+        tt = eng.trip_times.cpu().numpy()
+        if env is not None:
+            return tt[env, :min(int(n[env]), eng.trip_cap)].copy()
+        return [tt[k, :min(int(n[k]), eng.trip_cap)].copy() for k in range(eng.E)]
 
     def cars_on_roads(self):
         return self.engine.cars_on_roads()

@@ -53,6 +53,13 @@ class VecRemiRepeater(VecWrapper):
 
     def step(self, actions):
         inner = self.venv
+        # validate mode: what the reference's Repeater puts into info (traffic_test.py:41-46), for every env at once:
+        # `self.info['light_times']` float32 [E, I], 0 where the action flips nothing
+        eng = getattr(inner, 'engine', None)
+        if eng is not None and eng.validate and hasattr(inner, 'light_times'):
+            self.info = {'light_times': inner.light_times(actions)}
+        else:
+            self.info = None
         if hasattr(inner, 'agent_step'):
             return inner.agent_step(actions, self.repeat_count, remi=self.remi)
         r, i = inner.r, inner.I

@@ -153,8 +153,8 @@ def roofline(a, c, eng, E, prof, prof_updates, chunk, dt, updates):
     if 2 * (eng.pair_ticks()) >= K and kernel.startswith("k_move_tt"):
         kernel = "k_move_tt"
     call = min(chunk, K)                                                # ticks per tfx_step call
-    tpl = (call if kernel in ("k_res", "k_env") else 2 if kernel == "k_move_tt" else 1)     # ticks per LAUNCH
-    passes = (tpl + 1) // 2 if kernel in ("k_env", "k_move_tt") else tpl     # trips of the cars through HBM per launch
+    tpl = (call if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)     # ticks per LAUNCH
+    passes = 1                                                                  # trips of the cars through HBM per launch
     launch_ms = move_ms * tpl
     full = E == c["envs"]
     if kernel == "k_res":
@@ -191,9 +191,7 @@ def roofline(a, c, eng, E, prof, prof_updates, chunk, dt, updates):
             "timed_region": {"GBs": region_bytes / region_s / 1e9, "frac": region_bytes / region_s / 1e9 / HBM_PEAK_GBS},
             "measured": "HIP events on the launch stream around every launch of the kernel, in a second pass over "
                         "the same K ticks right after the timed regions (no events inside a timed region; the env "
-                        "range is not split over two streams while a launch is timed).  k_env: one launch = all the "
-                        "ticks of a tfx_step call (the cars make (ticks + 1) // 2 trips through HBM, the per-road words "
-                        "stay in LDS and are charged at the model's 48 B per road and tick all the same)"}
+                        "range is not split over two streams while a launch is timed)"}
 
 
 def numpy_baseline(name, budget_s=8.0):
@@ -315,6 +313,8 @@ def main():
                     help="N = 1 with everything a rank of an N > 1 run does: an RCCL process group (of one rank), the "
                          "snapshot + gather every %d ticks, barriers and reductions" % GATHER_EVERY)
     ap.add_argument("--no-numpy-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps ticks each (fenced); the line reports their median and the spread")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed ticks run right after the prefill, as part of the workload's setup and before the W "
                          "warm-up steps (default: the workload's, gym_traffic/workload.py SETTLE_TICKS; 0 = none)")
@@ -406,18 +406,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # Timed region: nothing but the K ticks (no HIP events in it - round 2 recorded three per pair of ticks there).
+    # Timed regions: nothing but the K ticks (no HIP events in them), REPEATS times, each fenced on both sides (barrier +
+    # device synchronisation); `value` is the MEDIAN region, `spread` the slowest and the fastest - one region of 20 ticks
+    # is 8 ms, and box to box and run to run the same binary moves by a few percent.
     run(a.warmup)
-    eng.reset_counters()
-    pair_ticks0, split_ticks0 = eng.pair_ticks(), eng.split_ticks()
+
+    # Agent decisions, MEASURED: the fused 10-tick decision (Repeater + Remi, tfx_agent_step) under the same rules,
+    # before the timed regions (later the benchmark's entry roads run full, and an env that overflows in the first tick
+    # of a decision stands still for the rest of it - `if done: break` - which would time decisions that do nothing)
+    n_dec = 5
+    eng.agent_step(GATHER_EVERY, remi=True)
     fence()
     t0 = time.perf_counter()
-    run(a.steps)
+    for _ in range(n_dec):
+        adone = eng.agent_step(GATHER_EVERY, remi=True)[2]
     fence()
-    dt = time.perf_counter() - t0
-    updates = eng.vehicle_updates()
-    pair_ticks = eng.pair_ticks() - pair_ticks0
-    split_ticks = eng.split_ticks() - split_ticks0
+    dt_agent = time.perf_counter() - t0
+    agent_done = int(adone.sum().item())
+
+    pair_ticks0, split_ticks0 = eng.pair_ticks(), eng.split_ticks()
+    regions = []
+    for _ in range(max(1, a.repeats)):
+        eng.reset_counters()
+        fence()
+        t0 = time.perf_counter()
+        run(a.steps)
+        fence()
+        regions.append((time.perf_counter() - t0, eng.vehicle_updates()))
+    pair_ticks = (eng.pair_ticks() - pair_ticks0) // len(regions)
+    split_ticks = (eng.split_ticks() - split_ticks0) // len(regions)
 
     # Roofline pass: the SAME K ticks again, now with HIP events on the launch stream around every launch of the
     # kernel that moves the cars (tfx_profile).  While it is timed a launch owns the chip: the handle does not
@@ -432,12 +449,20 @@ def main():
     eng.profile(0)
 
     red_dev = torch.device("cpu") if rehearsal else device
-    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-    uu = torch.tensor([updates], dtype=torch.float64, device=red_dev)
+    tt = torch.tensor([r[0] for r in regions] + [dt_agent], dtype=torch.float64, device=red_dev)
+    uu = torch.tensor([float(r[1]) for r in regions], dtype=torch.float64, device=red_dev)
+    t_min = tt.clone()
     if dist_on:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)        # every region: the slowest rank's time
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN)
         dist.all_reduce(uu, op=dist.ReduceOp.SUM)
-    dt_max, total_updates = float(tt.item()), float(uu.item())
+    times, totals = tt[:-1].tolist(), uu.tolist()
+    rates = [u / t for u, t in zip(totals, times)]
+    order = sorted(range(len(rates)), key=lambda i: rates[i])
+    mid = order[(len(order) - 1) // 2]                   # the median region (the lower one of an even count)
+    dt_max, total_updates = times[mid], totals[mid]
+    dt, updates = regions[mid]
+    dt_agent_max = float(tt[-1].item())
 
     if rank == 0:
         K = a.steps
@@ -454,7 +479,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.describe(a.config) + ", %d untimed settle ticks after the prefill" % settle,
+            "config": {"workload": wl.describe(a.config), "settle_ticks": settle,
                        "envs_per_gpu": E,
                        "grid": "%dx%d" % (c["m"], c["n"]), "cars_per_road_max": c["capacity"] - 2,
                        "car_layout": eng.layout,
@@ -462,14 +487,27 @@ def main():
                            world, ", one %s gather of (obs|reward|done) to rank 0 every %d ticks, double-"
                            "buffered on a side stream" % ("gloo (rehearsal)" if rehearsal else "RCCL", GATHER_EVERY)
                            if gather is not None else "")},
+            # every timed region of K ticks (fenced), the line's value being their median
+            "repeats": len(rates), "spread": [min(rates), max(rates)],
+            "ms_per_step_spread": [min(times) / K * 1e3, max(times) / K * 1e3],
             "env_steps_per_sec": world * E * K / dt_max,
-            "agent_steps_per_sec": world * E * K / dt_max / GATHER_EVERY,   # one decision = 10 ticks
+            # measured through tfx_agent_step (one decision = %d ticks + remi), not derived from the ticks above
+            "agent_steps_per_sec": world * E * n_dec / dt_agent_max,
+            "agent_decision_ms": dt_agent_max / n_dec * 1e3,
+            "agent_decisions_timed": n_dec, "agent_envs_done_in_last_decision": agent_done,
+            "regions": [{"ms": t * 1e3, "vehicle_updates": u} for t, u in zip(times, totals)],
             "mean_live_cars_per_road": updates / K / (E * eng.R),
             "ticks_in_two_tick_passes": pair_ticks,
             "ticks_split_over_two_streams": split_ticks,
             "ticks_per_call": min(chunk, K),
-            "roofline": roofline(a, c, eng, E, prof, prof_updates, gather is not None, dt_max, updates),
+            "roofline": roofline(a, c, eng, E, prof, prof_updates, chunk, dt_max, updates),
         }
+        if dist_on:
+            # what a scaling curve needs beside the aggregate: the ranks' own times for the median region
+            out["per_rank_ms_per_step"] = {"max": dt_max / K * 1e3, "min": float(t_min[mid].item()) / K * 1e3}
+            out["t_max_over_t_min"] = dt_max / max(1e-12, float(t_min[mid].item()))
+            out["rccl_ranks_seen"] = dist.get_world_size() if not rehearsal else 0
+            out["gather_ms_per_snapshot"] = gather.ms_per_snapshot() if gather is not None else None
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config)
             if not a.no_numpy_baseline:

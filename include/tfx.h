@@ -260,14 +260,6 @@ int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
  * second tick's inputs are produced on the device in between (tfx_set_poisson, TFX_ACTION_GREEDY).  TFX_TAIL=0
  * turns it off, TFX_TAIL=2 forces it at any batch size; results are bit-identical. */
 int tfx_tail_ticks(tfx_handle h, int64_t *ticks);
-/* Ticks of this handle that ran in k_env (csrc/tfx_env.hpp): ONE launch per tfx_step / tfx_agent_step call, a workgroup
- * per env for all the ticks of the call - the cars streamed from HBM in two-tick passes, the env's ring words (leading,
- * lastcar, the tails, the road records, the lights) resident in LDS from the first tick to the last.  Taken on its own
- * for calls of two ticks or more on the transposed layout from two envs per compute unit on, when an env's words fit a
- * workgroup's LDS (28 bytes per road: up to ~5 800 roads) and every tick's inputs exist before the call (everything
- * but the Poisson stream inside agent steps); results are bit-identical to the per-tick kernels.  TFX_ENVK=0 turns it
- * off, TFX_ENVK=2 forces it at any batch size. */
-int tfx_env_ticks(tfx_handle h, int64_t *ticks);
 /* Ticks of tfx_step calls that ran as two halves of the env range, the second half on a stream the handle owns
  * (forked from and joined to the caller's stream with events, so the call keeps its stream semantics): the
  * latency-bound per-road launch of one half then runs under the other half's pass over the cars.  Used for calls

@@ -256,33 +256,55 @@ def test_arrival_streams_threads_do_not_change_the_streams(monkeypatch):
     assert a.random_state(699).get_state()[2] == b.random_state(699).get_state()[2]
 
 
-def test_pmc_traffic_is_reported_only_for_the_profiled_sources(tmp_path, monkeypatch):
-    """bench.py's roofline.traffic comes from a committed rocprofv3 summary; it must vanish (null) as soon
-    as the kernel sources differ from the ones that were profiled, or the kernel / workload is another."""
+def test_pmc_traffic_is_reported_only_for_the_profiled_code(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 summary; it must vanish (null) as soon as the
+    machine code of that kernel in the library differs from the code that was profiled (tools/kernel_hash.py), or the
+    kernel / workload is another.  pmc_summary.py refuses to write a summary for counters that did not come with the
+    hash recorded on the box - there is no hand stamp."""
     import json
     import os
+    import subprocess
     import sys
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     sys.path.insert(0, ROOT)
     import bench
-    import pmc_summary
-    h = pmc_summary.csrc_hash()
-    assert len(h) == 16 and h == pmc_summary.csrc_hash()
+    import kernel_hash
+    hs = kernel_hash.kernel_hashes()
+    assert {"k_move_tt", "k_tail", "k_res", "k_move_t", "k_advance"} <= set(hs) and all(len(v) == 16 for v in hs.values())
+    assert hs == kernel_hash.kernel_hashes()
+    assert kernel_hash.family("_ZN3tfx9k_move_ttILb1ELb0ELb0ELb0EEEvNS_3DevEii") == "k_move_tt"
     prof = tmp_path / "profiles"
     prof.mkdir()
-    good = {"kernel": "k_move_t", "csrc_hash": h, "hbm_bytes_per_tick": 123.0}
+    good = {"kernel": "k_move_t", "kernel_hash": hs["k_move_t"], "hbm_bytes_per_tick": 123.0}
     (prof / "pmc_cfgX.json").write_text(json.dumps(good))
-    (prof / "pmc_cfgY.json").write_text(json.dumps(dict(good, csrc_hash="0" * 16)))
+    (prof / "pmc_cfgY.json").write_text(json.dumps(dict(good, kernel_hash="0" * 16)))
+    (prof / "pmc_cfgW.json").write_text(json.dumps({"kernel": "k_move_t", "csrc_hash": "x" * 16, "hbm_bytes_per_tick": 1.0}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.load_pmc_traffic("cfgX", "k_move_t") == 123.0
     assert bench.load_pmc_traffic("cfgX", "k_res") is None          # another kernel moved the cars
-    assert bench.load_pmc_traffic("cfgY", "k_move_t") is None       # profiled on other sources
+    assert bench.load_pmc_traffic("cfgY", "k_move_t") is None       # other code was profiled
+    assert bench.load_pmc_traffic("cfgW", "k_move_t") is None       # a summary without the code's hash (earlier rounds)
     assert bench.load_pmc_traffic("cfgZ", "k_move_t") is None       # never profiled
-    # the committed summaries carry a hash and name their kernel
-    for cfg in ("cfg1", "cfg2", "cfg4"):
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_%s.json" % cfg)))
-        assert len(d["csrc_hash"]) == 16 and d["kernel"] in pmc_summary.MOVERS and d["hbm_bytes_per_tick"] > 0
+    # counters without the hash taken on the box: no summary
+    pm = tmp_path / "run" / "cfg_fetch"
+    pm.mkdir(parents=True)
+    (pm / "p_counter_collection.csv").write_text(
+        "Kernel_Name,Counter_Name,Counter_Value\n"
+        "\"void tfx::k_move_t<4, 3, false>(tfx::Dev, int)\",FETCH_SIZE,10\n"
+        "\"void tfx::k_move_t<4, 3, false>(tfx::Dev, int)\",WRITE_SIZE,10\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--round", "rXX", "--config", "cfgT",
+                        "--pmc", str(pm), "--kernel", "k_move_t", "--out", str(tmp_path / "out")],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode != 0 and "kernel_hashes.json" in (r.stderr + r.stdout)
+    assert not os.path.exists(str(tmp_path / "out"))
+    # ... and with it: the summary carries THAT hash, whatever the library in this tree looks like
+    (tmp_path / "run" / "kernel_hashes.json").write_text(json.dumps({"k_move_t": "feedfacefeedface"}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--round", "rXX", "--config", "cfgT",
+                        "--pmc", str(pm), "--kernel", "k_move_t", "--out", str(tmp_path / "out")],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.load(open(str(tmp_path / "out" / "pmc_cfgT.json")))["kernel_hash"] == "feedfacefeedface"
 
 
 def test_pmc_summary_tells_the_move_kernels_apart():

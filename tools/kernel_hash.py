@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Hashes of the MACHINE CODE of the kernels in libtfx_hip.so, per kernel family.
 
-    python tools/kernel_hash.py            # {"k_env": "...", "k_move_tt": "...", ...} as JSON
-    python tools/kernel_hash.py k_env      # one hash
+    python tools/kernel_hash.py            # {"k_tail": "...", "k_move_tt": "...", ...} as JSON
+    python tools/kernel_hash.py k_tail     # one hash
 
 The gfx950 code object is taken out of the shared library (llvm-objdump --offloading), disassembled, and the
 instruction text of every instantiation of a kernel template (addresses and encodings stripped) is hashed, sorted by

@@ -9,9 +9,11 @@ profiles/<round>_pmc_<config>.csv (mean counter value per kernel) and profiles/p
 (--kernel, default: the one of ours with the largest total time) from FETCH_SIZE and WRITE_SIZE,
 corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 - both are in KiB;
 FETCH_SIZE counts 128-byte requests as 64 bytes for wide streaming reads, so it is doubled;
-WRITE_SIZE is exact for streaming stores.  The json carries `csrc_hash` (tools/pmc_summary.py
---hash prints the current one): bench.py reports the traffic only while the kernels' sources are
-the ones that were profiled.
+WRITE_SIZE is exact for streaming stores.  The json carries `kernel_hash`: the hash of the measured kernel's MACHINE
+CODE in the library that ran under the profiler, recorded on the box next to the counters (kernel_hashes.json in the
+profile directory, written by tools/profile_round.sh with tools/kernel_hash.py).  This script only copies it - it
+refuses to write a summary for counters that came without one - so a summary cannot be re-stamped for other code;
+bench.py reports the traffic only while the library it drives has the same hash for that kernel.
 """
 import argparse
 import collections
@@ -63,7 +65,7 @@ def csrc_hash():
 def short(name):
     if "k_move_tt<false" in name:
         return "k_move_tt1"          # the one-tick form that ends a call of two-tick passes
-    for k in MOVERS + ("k_tail", "k_edge", "k_advance", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
+    for k in MOVERS + ("k_tail", "k_edge", "k_advance", "k_risk", "k_tick_add", "k_reset", "k_refresh", "k_remi", "k_done", "k_cars_on_roads",
                        "k_poisson", "k_greedy", "k_agent_obs"):
         if k + "<" in name or k + "(" in name or name.strip().endswith(k):
             return k
@@ -85,12 +87,22 @@ def main():
                     help="ticks one launch of that kernel covers (k_res: the n of tfx_step(n); k_move_tt: 2)")
     ap.add_argument("--read-bytes-expected", type=float, default=0.0,
                     help="bytes the kernel is known to read per launch (for the record of the FETCH_SIZE factor)")
-    ap.add_argument("--hash", action="store_true", help="print the current csrc hash and exit")
+    ap.add_argument("--hash", action="store_true", help="print the current source hash and exit (informational)")
+    ap.add_argument("--out", default=None, help="directory the summaries go to (default: profiles/)")
+    ap.add_argument("--hashes", default=None,
+                    help="kernel_hashes.json recorded on the box by the profile run (default: next to the --pmc directories)")
     a = ap.parse_args()
     if a.hash:
         print(csrc_hash())
         return
-    out = os.path.join(ROOT, "profiles")
+    hashes = None
+    if a.pmc:  # counters travel with the hash of the code they measured, or not at all
+        hpath = a.hashes or os.path.join(os.path.dirname(os.path.abspath(a.pmc[0].rstrip("/"))), "kernel_hashes.json")
+        if not os.path.exists(hpath):
+            raise SystemExit("pmc_summary: %s is missing - these counters were not taken together with the hash of the "
+                             "code they measured (tools/profile_round.sh writes it on the box); no summary written" % hpath)
+        hashes = json.load(open(hpath))
+    out = a.out or os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     total_ns = collections.Counter()
     if a.kt:
@@ -125,7 +137,10 @@ def main():
                 v = sorted(v)
                 return 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
             fetch, write = med(agg[(mv, "FETCH_SIZE")]), med(agg[(mv, "WRITE_SIZE")])
-            js = {"kernel": mv, "config": a.config, "round": a.round, "csrc_hash": csrc_hash(),
+            khash = hashes.get(mv)
+            if not khash:
+                raise SystemExit("pmc_summary: no hash for %s was recorded with these counters" % mv)
+            js = {"kernel": mv, "config": a.config, "round": a.round, "kernel_hash": khash,
                   "ticks_per_launch": a.ticks_per_launch,
                   "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
                   "read_bytes": fetch * 1024 * 2, "write_bytes": write * 1024,

@@ -6,7 +6,7 @@
 // leading[e] before e's own pops iff p < e.  A road that pops more than two cars, or a handed-off car
 // that would itself leave again in the same tick ("far"), sends the env to advance_env_serial_t.
 // After the second tick of a two-tick pass (k_edge, tfx_move_tt.hpp) a road that popped keeps its survivors
-// where they were: the rows of its column start rec_hb(rec.y) rows down, and so do the appends here.
+// where they were: the rows of its column start d.hb[road] rows down, and so do the appends here.
 #pragma once
 #include "tfx_common.hpp"
 #include "tfx_move_t.hpp"
@@ -23,7 +23,7 @@ __device__ __forceinline__ void compact_head_rows(const Dev &d, int id, int hb, 
     d.xv[tpos(d, id, q)] = d.xv[tpos(d, id, q + hb)];
     if (WP && d.w) d.w[tpos(d, id, q)] = d.w[tpos(d, id, q + hb)];
   }
-  d.rec[id].y &= ~(3 << 28);
+  d.hb[id] = 0;
 }
 
 template <bool HET = false, bool WP = true>
@@ -45,7 +45,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
     const int idp = env * d.R + p;
     const int k_p = rec_kpop(d.rec[idp].x);
     if (k_p > 0) {
-      int hb = rec_hb(rc.y);
+      int hb = d.hb[id];
       if (hb > 0 && hb + m + k_p > d.trows) {
         compact_head_rows<WP>(d, id, hb, m);
         hb = 0;
@@ -122,7 +122,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     if (HET) d.taila[env * d.R + e] = rec_taila(d.rec[env * d.R + e].w);
   }
   // row k of a road's column, counted from its first live row
-  auto rowb = [&](int idq, int k) { return tpos(d, idq, k + rec_hb(d.rec[idq].y)); };
+  auto rowb = [&](int idq, int k) { return tpos(d, idq, k + d.hb[idq]); };
 
   // the j-th popped car of road `idq` while its pops are still pending
   auto popped = [&](int idq, int j, float &cw) {
@@ -148,7 +148,7 @@ __device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) 
     const int ta = HET ? d.taila[idn] : 0;
     const float tl = HET ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = HET ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
     const float start = (lcn != ldn) ? (d.tailx[idn] - tl) - ts0 : INFINITY;
-    if (pos != ldn && rec_hb(rn.y) + base + phys >= d.trows) compact_head_rows<WP>(d, idn, rec_hb(rn.y), phys);  // (then base = 0)
+    if (pos != ldn && d.hb[idn] + base + phys >= d.trows) compact_head_rows<WP>(d, idn, d.hb[idn], phys);  // (then base = 0)
     if (pos != ldn) {
       const float xv = (start < car.x) ? start : car.x;
       d.xv[rowb(idn, base + phys)] = make_float2(xv, car.y);

@@ -53,7 +53,10 @@ struct Dev {
   const int *road_slot, *slot_road;
   int G;
   int trows;  // rows (of 64 (x, v) pairs) a tile occupies in T: >= C - 2
-  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows | head rows << 28 | uncompacted << 30, bits of post-move tail x, live cars}
+  int4 *rec;      // per road: {pops k | head slot << 16, spawn overflows | uncompacted << 30, bits of post-move tail x, live cars}
+  // transposed layout: rows at the top of a road's column that hold no car (0..TFX_KP; see rec_hb) - a byte per road
+  // of its own since round 4: the pass reads one byte instead of a 16-byte record, k_tail writes one back
+  uint8_t *hb;
   int4 *rec2;     // per road, two-tick pass only (tfx_move_tt.hpp): {bits of the tail's v after the first tick, waiting and
                   //   detected counts of the second tick so far, bits of the tail's x after the second tick}
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; the first TFX_KP = 2 cars that
@@ -73,7 +76,6 @@ struct Dev {
   int risk_stride;  // words from one plane to the other (the whole handle's E, also inside the half of a split call)
   int4 *exp_pad;    // TFX_EXP_PAD=n (timing experiments): k_tail writes n extra 16-byte words per road here
   int exp_pad_n;
-  int no_stamps;    // k_env: the workgroup decides about its env's pairs itself, the stamps are not consulted
   int *risk_any;  // [2], one per plane of env_risk: == tick+1 when any env is marked for the pair starting at `tick`
   unsigned long long *veh;
   int *tickA, *tickB;
@@ -356,10 +358,9 @@ __device__ __forceinline__ int rec_kpop(int rx) { return rx & 0xffff; }
 __device__ __forceinline__ int rec_y(int ovf_sp, bool unc) { return ovf_sp | (unc ? (1 << 30) : 0); }
 __device__ __forceinline__ int rec_ovf_sp(int ry) { return ry & 0x0fffffff; }
 __device__ __forceinline__ bool rec_unc(int ry) { return (ry >> 30) & 1; }
-// rec.y bits 28-29: rows at the top of the road's column that hold no car (transposed layout).  Only k_edge
-// leaves any: the second tick of a two-tick pass pops without compacting; the next move kernel of the same
-// call reads past them and writes the column compacted again (tfx_move_tt.hpp).
-__device__ __forceinline__ int rec_hb(int ry) { return (ry >> 28) & 3; }
+// d.hb[road]: rows at the top of the road's column that hold no car (transposed layout).  Only the second tick of a
+// two-tick pass leaves any (edge_tile: it pops without compacting); the next move kernel reads past them and writes the
+// column compacted again (tfx_move_tt.hpp).
 __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 // rec.w: cars on the road during the move (incl. this tick's arrivals) | table row of the last of them << 16
 __device__ __forceinline__ int rec_ntot(int rw) { return rw & 0xffff; }

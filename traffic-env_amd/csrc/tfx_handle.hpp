@@ -51,10 +51,6 @@ struct tfx_handle_s {
   int grid_adv = 0;
   int grid_tail = 0, grid_tail_half = 0;  // k_tail: workgroups of 256 lanes / of 128 (the halves of a split call)
   int tail_threads = 256, tail_threads_half = 128;
-  // k_env (tfx_env.hpp): a workgroup per env for all the ticks of a call.  TFX_ENVK=0 never, 2 at any batch size
-  int envk = 0;  // (measured 35 % slower than pairs + k_tail at cfg2: off unless forced)
-  int grid_env = 0, env_threads = 0;
-  long long env_ticks = 0;    // ticks run by k_env since tfx_create
   int tail = 1;               // k_tail after a two-tick pass (tfx_tail.hpp): TFX_TAIL=0 never, 2 at any batch size
   // calls of pairs run as TWO halves of the env range, the second on a stream of the handle's own: the latency-bound
   // per-road launch of one half (k_tail) runs under the other half's car pass (split_usable)
@@ -91,7 +87,7 @@ struct tfx_handle_s {
   long long fused_ticks = 0;   // ticks run by k_res since tfx_create
   long long pair_ticks = 0;    // ticks run as two-tick passes since tfx_create
   long long tail_ticks = 0;    // ... of which k_tail finished the pair (tfx_tail.hpp)
-  long long ag_fused = 0, ag_pair = 0, ag_env = 0;  // what ONE replay of the captured agent-step graph adds to the counters
+  long long ag_fused = 0, ag_pair = 0;  // what ONE replay of the captured agent-step graph adds to the two above
   const char *step_kernel = "";  // the kernel that moved the cars in the last tick (tfx_step_kernel)
   // TFX_MOVE_VARIANT selects the move kernel for A/B runs (see launch_move); 0 = best known
   int move_variant = 0;

@@ -27,27 +27,24 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   hipStream_t st = (hipStream_t)stream;
   const Dev &d = h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
-  const bool envk = !res_usable(h, n_ticks) && env_usable(h, n_ticks);
-  const bool split = !envk && !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
+  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
   if (split) {
     if (int rc = ensure_split(h, st)) return rc;
   }
-  // (a batch big enough for either is not bound by its launches: enqueued eagerly)
-  if (!h->use_graph || split || (envk && h->envk != 2)) {
-    long long nf = 0, np = 0, ne = 0;
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np, ne, split, envk);
+  if (!h->use_graph || split) {
+    long long nf = 0, np = 0;
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, st, nf, np, split);
     if (rc == TFX_OK) {
       h->fused_ticks += nf;
       h->pair_ticks += np;
-      h->env_ticks += ne;
       if (split) h->split_ticks += n_ticks;
     }
     return rc;
   }
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[640];
-  snprintf(key, sizeof key, "%d|%llu|%u|%u|%d.%d.%d.%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
-           (int)envk, h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, h->ps.regular, h->ps.every, h->ps.burst, (int)h->poisson,
+  snprintf(key, sizeof key, "%llu|%u|%u|%d.%d.%d.%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
+           h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, h->ps.regular, h->ps.every, h->ps.burst, (int)h->poisson,
            (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, (void *)aobs,
            (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
            (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
@@ -64,11 +61,6 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       (void)launch_advance(h, 0, nullptr);
       h->size_only = false;
     }
-    if (envk) {
-      h->size_only = true;
-      (void)launch_env(h, n_ticks, nullptr, true);
-      h->size_only = false;
-    }
     if (!res_usable(h, n_ticks) && pairs_usable(h)) {
       h->size_only = true;
       (void)launch_move_tt<true, true>(h, 0, nullptr);
@@ -78,7 +70,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       (void)edge_grid(h);
     }
     HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream, h->ag_fused, h->ag_pair, h->ag_env, false, envk);
+    const int rc = agent_sequence(h, n_ticks, remi, aobs, areward, adone, h->ag_stream, h->ag_fused, h->ag_pair);
     hipGraph_t g = nullptr;
     const hipError_t ce = hipStreamEndCapture(h->ag_stream, &g);
     if (rc != TFX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -90,7 +82,6 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   HIPCHK(hipGraphLaunch(h->ag_exec, st));
   h->fused_ticks += h->ag_fused;  // (the capture ran no kernel: every replay counts)
   h->pair_ticks += h->ag_pair;
-  h->env_ticks += h->ag_env;
   return TFX_OK;
 }
 
@@ -145,7 +136,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
   if (const char *tv = getenv("TFX_TAIL")) h->tail = atoi(tv);
   if (const char *sv = getenv("TFX_SPLIT")) h->split = atoi(sv);
-  if (const char *kv = getenv("TFX_ENVK")) h->envk = atoi(kv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -224,6 +214,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_outw = off;  off = align_up(off + (d.layout == 1 && cfg->planes == 3 ? n_opairs * sizeof(float) : 0), 256);
   const size_t o_lead = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_taila = off; off = align_up(off + (het ? ER * sizeof(int) : 0), 256);
+  const size_t o_hb = off;    off = align_up(off + (d.layout == 1 ? ER : 0), 256);
   const size_t o_misc = off;  off = align_up(off + 128, 256);
   const size_t o_veh = off;   off = align_up(off + (size_t)VEH_SLOTS * VEH_STRIDE * sizeof(unsigned long long), 256);
   if (hipMalloc(&h->dev_scratch, off) != hipSuccess) {
@@ -247,6 +238,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.outb = (float2 *)(base + o_outb);
   d.outw = (float *)(base + o_outw);
   d.leadx = (float *)(base + o_lead);
+  d.hb = d.layout == 1 ? (uint8_t *)(base + o_hb) : nullptr;
   d.het = het ? 1 : 0;
   d.taila = (int *)(base + o_taila);
   if (het) {
@@ -744,12 +736,6 @@ int tfx_pair_ticks(tfx_handle h, int64_t *ticks) {
 int tfx_tail_ticks(tfx_handle h, int64_t *ticks) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->tail_ticks;
-  return TFX_OK;
-}
-
-int tfx_env_ticks(tfx_handle h, int64_t *ticks) {
-  if (int rc = check_handle(h, false)) return rc;
-  if (ticks) *ticks = h->env_ticks;
   return TFX_OK;
 }
 

@@ -10,7 +10,6 @@
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_tail.hpp"
-#include "tfx_env.hpp"
 
 namespace {
 
@@ -424,6 +423,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   if (d.n_trips) s.n_trips = d.n_trips + L;
   s.rec = d.rec + L * R;
   s.rec2 = d.rec2 + L * R;
+  if (d.hb) s.hb = d.hb + L * R;
   if (d.exp_pad) s.exp_pad = d.exp_pad + L * R;
   s.tailx = d.tailx + L * R;
   if (d.taila) s.taila = d.taila + L * R;
@@ -471,7 +471,7 @@ bool split_usable(tfx_handle h, int n_ticks) {
 // Round 3's unstaged k_tail: alone on the chip 256 lanes and as many workgroups as fit were best; as one half of a
 // split call, next to the other half's pass, 128 lanes (they fit the gaps the pass leaves).
 template <bool GREEDY, bool AGENT, bool W, bool HET>
-int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int risk_next) {
+int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int flags) {
   auto kern = k_tail<GREEDY, AGENT, W, HET>;
   const size_t lds = tail_lds_bytes(h->d.R, h->d.I, HET);
   // The attribute belongs to the FUNCTION, not to the handle: only ever raised (see res_try)
@@ -498,88 +498,26 @@ int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int risk_next) {
   TFX_INJECT(h);
   const bool halves = h->split_half >= 0;
   const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? h->tail_threads_half : h->tail_threads);
-  hipLaunchKernelGGL(kern, g, b, lds, st, h->d, tidx, risk_next);
+  hipLaunchKernelGGL(kern, g, b, lds, st, h->d, tidx, flags);
   HIPCHK(hipGetLastError());
   return TFX_OK;
 }
 
-int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false, int risk_next = 0) {
+int launch_tail(tfx_handle h, int tidx, hipStream_t st, bool agent = false, int flags = TAIL_LAST) {
   const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
   switch (sel) {
-    case 12: return launch_tail_as<false, false, true, true>(h, tidx, st, risk_next);
-    case 13: return launch_tail_as<true, false, true, true>(h, tidx, st, risk_next);
-    case 14: return launch_tail_as<false, true, true, true>(h, tidx, st, risk_next);
-    case 15: return launch_tail_as<true, true, true, true>(h, tidx, st, risk_next);
-    case 0: return launch_tail_as<false, false, false, false>(h, tidx, st, risk_next);
-    case 1: return launch_tail_as<true, false, false, false>(h, tidx, st, risk_next);
-    case 2: return launch_tail_as<false, true, false, false>(h, tidx, st, risk_next);
-    case 3: return launch_tail_as<true, true, false, false>(h, tidx, st, risk_next);
-    case 4: return launch_tail_as<false, false, true, false>(h, tidx, st, risk_next);
-    case 5: return launch_tail_as<true, false, true, false>(h, tidx, st, risk_next);
-    case 6: return launch_tail_as<false, true, true, false>(h, tidx, st, risk_next);
-    default: return launch_tail_as<true, true, true, false>(h, tidx, st, risk_next);
-  }
-}
-
-// k_env (tfx_env.hpp): one workgroup per env takes the env through ALL the ticks of a call - the cars streamed from
-// HBM, the ring words in LDS.  For calls of two ticks or more on the transposed layout when an env's words fit a
-// workgroup's LDS, the inputs of every tick exist before the call (not the Poisson stream tick by tick: agent steps),
-// and there are enough envs to fill the chip with whole workgroups (below that the tiles of k_move_tt spread better).
-bool env_usable(tfx_handle h, int n_ticks) {
-  const Dev &d = h->d;
-  if (!h->envk || d.layout != 1 || n_ticks < 2 || h->move_variant != 0 || h->res_epb > 0 || !h->pairs) return false;
-  if (h->poisson && d.spawn_stride == 0) return false;
-  if (env_lds_bytes(d.R, d.I, h->het) > TAIL_LDS_MAX) return false;
-  return h->envk == 2 || d.E >= 2 * h->n_cu;
-}
-
-template <bool GREEDY, bool AGENT, bool W, bool HET>
-int launch_env_as(tfx_handle h, int n_ticks, hipStream_t st) {
-  auto kern = k_env<GREEDY, AGENT, W, HET>;
-  const size_t lds = env_lds_bytes(h->d.R, h->d.I, HET);
-  static size_t granted = 64 * 1024;  // (the attribute belongs to the function: only ever raised, see res_try)
-  if (lds > granted) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    granted = lds;
-  }
-  if (h->grid_env == 0) {
-    int threads = 64 * ENV_WAVES;
-    if (const char *tv = getenv("TFX_ENV_THREADS"))
-      if (atoi(tv) >= 64 && atoi(tv) <= ENV_MAX_THREADS && atoi(tv) % 64 == 0) threads = atoi(tv);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (const char *pc = getenv("TFX_ENV_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
-    long g = (long)h->n_cu * per_cu;
-    if (g > h->d.E) g = h->d.E;
-    h->grid_env = (int)(g < 1 ? 1 : g);
-    h->env_threads = threads;
-  }
-  if (h->size_only) return TFX_OK;
-  TFX_INJECT(h);
-  h->step_kernel = "k_env";
-  hipLaunchKernelGGL(kern, dim3(h->grid_env), dim3(h->env_threads), lds, st, h->d, n_ticks);
-  HIPCHK(hipGetLastError());
-  // every workgroup reads the clock at its start: it moves in a launch of its own
-  hipLaunchKernelGGL(k_tick_add, dim3(1), dim3(1), 0, st, h->d, n_ticks);
-  HIPCHK(hipGetLastError());
-  return TFX_OK;
-}
-
-int launch_env(tfx_handle h, int n_ticks, hipStream_t st, bool agent = false) {
-  const int sel = (h->greedy ? 1 : 0) | (agent ? 2 : 0) | (h->d.w ? 4 : 0) | (h->d.het ? 8 : 0);
-  switch (sel) {
-    case 12: return launch_env_as<false, false, true, true>(h, n_ticks, st);
-    case 13: return launch_env_as<true, false, true, true>(h, n_ticks, st);
-    case 14: return launch_env_as<false, true, true, true>(h, n_ticks, st);
-    case 15: return launch_env_as<true, true, true, true>(h, n_ticks, st);
-    case 0: return launch_env_as<false, false, false, false>(h, n_ticks, st);
-    case 1: return launch_env_as<true, false, false, false>(h, n_ticks, st);
-    case 2: return launch_env_as<false, true, false, false>(h, n_ticks, st);
-    case 3: return launch_env_as<true, true, false, false>(h, n_ticks, st);
-    case 4: return launch_env_as<false, false, true, false>(h, n_ticks, st);
-    case 5: return launch_env_as<true, false, true, false>(h, n_ticks, st);
-    case 6: return launch_env_as<false, true, true, false>(h, n_ticks, st);
-    default: return launch_env_as<true, true, true, false>(h, n_ticks, st);
+    case 12: return launch_tail_as<false, false, true, true>(h, tidx, st, flags);
+    case 13: return launch_tail_as<true, false, true, true>(h, tidx, st, flags);
+    case 14: return launch_tail_as<false, true, true, true>(h, tidx, st, flags);
+    case 15: return launch_tail_as<true, true, true, true>(h, tidx, st, flags);
+    case 0: return launch_tail_as<false, false, false, false>(h, tidx, st, flags);
+    case 1: return launch_tail_as<true, false, false, false>(h, tidx, st, flags);
+    case 2: return launch_tail_as<false, true, false, false>(h, tidx, st, flags);
+    case 3: return launch_tail_as<true, true, false, false>(h, tidx, st, flags);
+    case 4: return launch_tail_as<false, false, true, false>(h, tidx, st, flags);
+    case 5: return launch_tail_as<true, false, true, false>(h, tidx, st, flags);
+    case 6: return launch_tail_as<false, true, true, false>(h, tidx, st, flags);
+    default: return launch_tail_as<true, true, true, false>(h, tidx, st, flags);
   }
 }
 

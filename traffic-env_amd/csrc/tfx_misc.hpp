@@ -19,6 +19,7 @@ __global__ void k_reset(const Dev d, const int *phase_init, const uint8_t *mask)
       if (d.w) d.w[(size_t)id * d.C + 1] = 0.0f;
     } else {
       d.leadx[id] = INFINITY;
+      d.hb[id] = 0;
     }
     d.leading[id] = 1;
     d.lastcar[id] = 1;
@@ -51,7 +52,7 @@ __global__ void k_refresh(const Dev d) {
       d.tailx[id] = d.xv[(size_t)id * d.C + d.lastcar[id]].x;
     } else {
       const int n = ring_count(d.leading[id], d.lastcar[id], d.C);
-      const int hb = rec_hb(d.rec[id].y);
+      const int hb = d.hb[id];
       d.tailx[id] = (n > 0) ? d.xv[tpos(d, (int)id, n - 1 + hb)].x : 0.0f;
       if (d.het) d.taila[id] = (n > 0) ? side_arch(d.w[tpos(d, (int)id, n - 1 + hb)]) : 0;
     }
@@ -67,7 +68,7 @@ __global__ void k_export_ring(const Dev d, float2 *ring, float *ringw, uint8_t *
     const int ld = d.leading[id];
     const int n = ring_count(ld, d.lastcar[id], d.C);
     float2 *row = ring + (size_t)id * d.C;
-    const int hb = rec_hb(d.rec[id].y);  // rows a two-tick pass left empty at the top of the column (tfx_move_tt.hpp)
+    const int hb = d.layout == 1 ? d.hb[id] : 0;  // rows a two-tick pass left empty at the top of the column (tfx_move_tt.hpp)
     int slot = ld;
     for (int k = 0; k < n; ++k) {
       slot = wrap1(slot + 1, d.C);
@@ -99,7 +100,7 @@ __global__ void k_import_ring(const Dev d, const float2 *ring, const float *ring
       }
     }
     d.leadx[id] = row[ld].x;
-    d.rec[id].y &= ~(3 << 28);  // the column starts at row 0 again
+    d.hb[id] = 0;  // the column starts at row 0 again
   }
 }
 

@@ -15,7 +15,7 @@
 // the pops of t+1 and the road record k_advance(t+1) consumes.  Launch sequence of a pair:
 //   k_move_tt<true>(t)  k_advance(t)  [inputs of t+1]  k_edge(t+1)  k_advance(t+1)
 // and the state after it is bit for bit the state after k_move_t, k_advance, k_move_t, k_advance - except
-// that a road that popped in t+1 is not compacted: its live rows start rec_hb(rec.y) rows down (shifting a column
+// that a road that popped in t+1 is not compacted: its live rows start d.hb[road] rows down (shifting a column
 // is uncoalesced work; reading past two rows is free).  The next move kernel - another pair, or k_move_tt<false>,
 // the one-tick form, which every handle big enough for the pairs uses for ALL its single ticks - reads from there
 // and writes the column compacted; k_advance, the serial advance, tfx_export_ring and k_refresh honour the offset,
@@ -69,8 +69,7 @@ namespace tfx {
 // subtracts (the walk carries the lengths of cars k-1 and k-2 along with their new states)
 // One tile (64 roads of one env, lane = road) of a pass: every car through tick `tick` and - `two` - all but the roads'
 // heads and joiners through tick + 1 as well.  Returns the lane's vehicle-updates of tick `tick`.  Reads and writes the
-// ring words (leading, lastcar, tailx, rec, the light words) through `d`: the arrays themselves (k_move_tt) or a
-// workgroup's LDS copies of one env's (k_env, tfx_env.hpp).
+// ring words (leading, lastcar, tailx, rec, the light words) through `d`.
 template <bool TWO, bool AGENT, bool W, bool HET>
 __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const int env, const int lane, const int tick,
                                             const int tick_sp, const int tidx, const bool two, const float *s_arch) {
@@ -81,7 +80,7 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
   const int e = valid ? e_slot : 0;
   const int id = env * d.R + e;
   const bool run = valid && !(AGENT && env_frozen(d, env, tick));
-  const int hb = run ? rec_hb(d.rec[id].y) : 0;  // rows k_edge left empty at the top of the column
+  const int hb = run ? d.hb[id] : 0;  // rows the second tick of the last pair left empty at the top of the column
   const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
   const int n_old = run ? p.n_old : 0;
   const int n_sp = run ? p.n_tot - p.n_old : 0;
@@ -283,6 +282,7 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
                           n_tot | (HET ? last_a << 16 : 0));
     if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
     if (far || kpop > KP) d.env_flag[env] = tick + 1;
+    if (hb) d.hb[id] = 0;  // (the column was written compacted)
     if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
     return n_tot;
   }
@@ -337,7 +337,7 @@ __device__ __forceinline__ bool risk_lane(const Dev &d, long tile, int env, int 
   const int c_sp = ej >= 0 ? spawn_count(d, env, e, ej, tick_sp, tidx) : 0;
   bool risky = n + c_sp > C - 2;
   // how many cars could leave: a prefix of the cars that can reach the end of the road at all
-  const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)rec_hb(d.rec[id].y) * 64;
+  const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)d.hb[id] * 64;
   int pops = 0;
   for (int j = 0; j <= KP && j < n; ++j) {
     const float2 c = col[(size_t)j * 64];
@@ -380,13 +380,16 @@ __global__ __launch_bounds__(256) void k_risk(const Dev d, const int tidx) {
 // ownership as the pass, a few cars per road.  Returns the lane's vehicle-updates.
 // HET: heterogeneous cars - `arch` is the caller's LDS copy of the archetype table; a deferred car's row comes from its
 // side word (or from the spawner's draw), its leader's length travels along with the leader's old state
+// full_out = false (k_tail, every pair of a tfx_step call but the last): what nobody can read before the next pair
+// overwrites it is not stored - `passed` of the tick (outside agent steps, where it accumulates) and the fake leader's x
+// kept for tfx_export_ring; `detected` is stored all the same (an empty road keeps its last value, :199-201)
 template <bool AGENT, bool W = false, bool HET = false>
 __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int lane, int tick, int tick_sp, int tidx,
-                                         const float *arch = nullptr) {
+                                         const float *arch = nullptr, const bool full_out = true) {
   const int C = d.C;
   // (agent step: frozen envs stand still; risky envs took the first tick alone and get the second from a
   // one-tick launch of their own)
-  if (AGENT && ((!d.no_stamps && risk_word(d, env, tidx) == tick) || env_frozen(d, env, tick))) return 0;
+  if (AGENT && (risk_word(d, env, tidx) == tick || env_frozen(d, env, tick))) return 0;
   const int e = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
   if (e < 0) return 0;
   const int id = env * d.R + e;
@@ -500,13 +503,15 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     int *ob = d.obs + (size_t)env * d.obs_len;
     if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
     if (n_tot > 0) ob[d.r + e] = n_det;
-    ob[e] = AGENT ? ob[e] + kpop : kpop;
+    if (AGENT) ob[e] += kpop;
+    else if (full_out) ob[e] = kpop;
     if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
   }
-  d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc) | ((unc ? 0 : kpop) << 28),
+  if (!unc && kpop) d.hb[id] = (uint8_t)kpop;  // (0 before: the pass wrote the column compacted)
+  d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc),
                         __float_as_int(tail_x), n_tot | (HET ? last_a << 16 : 0));
   if (far || unc) d.env_flag[env] = tick + 1;
-  d.leadx[id] = p.xL;
+  if (full_out) d.leadx[id] = p.xL;
   return n_tot;
 }
 

@@ -73,10 +73,9 @@ struct SeqGuard {
 // split: the ticks run as two halves of the env range, the second on the handle's own stream (as step_chunk does for
 // tfx_step; launched eagerly - a batch big enough to split is not bound by its launches)
 int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *areward, uint8_t *adone,
-                   hipStream_t st, long long &n_fused, long long &n_pair, long long &n_env, bool split = false,
-                   bool envk = false) {
+                   hipStream_t st, long long &n_fused, long long &n_pair, bool split = false) {
   Dev &d = h->d;
-  n_fused = n_pair = n_env = 0;
+  n_fused = n_pair = 0;
   SeqGuard guard(h);
   if (res_usable(h, n_ticks)) {
     // every tick of the decision AND its tail (remi, observation, rewards, done flags) in one launch
@@ -93,15 +92,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   d.accum_rewards = remi ? 0 : 1;
   int rc = TFX_OK;
   const Dev whole = h->d;
-  if (envk) {
-    // the whole decision in one launch, a workgroup per env (tfx_env.hpp): the bound k_risk takes is evaluated inside,
-    // an env that overflows stops on the spot
-    rc = launch_env(h, n_ticks, st, true);
-    if (rc != TFX_OK) return rc;
-    n_pair = 2 * (n_ticks / 2);
-    n_env = n_ticks;
-  }
-  if (split && !envk) {
+  if (split) {
     h->size_only = true;  // (grids are sized for the whole range)
     (void)launch_move_tt<true, true>(h, 0, nullptr);
     (void)launch_move_tt<false, true>(h, 0, nullptr);
@@ -117,7 +108,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     if (int frc = guard.fork(st)) return frc;
   }
   hipStream_t user_st = st;
-  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK && !envk; ++half) {
+  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
     if (split) {
       const int n0 = whole.E / 2;
       h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
@@ -138,7 +129,8 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
         if (rc == TFX_OK && tail) {
           // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
-          rc = launch_tail(h, t, st, true, t + 3 < n_ticks ? 1 : 0);
+          // (TAIL_LAST on every pair: an env that overflows stands still from there on, with what its last pair stored)
+          rc = launch_tail(h, t, st, true, (t + 3 < n_ticks ? TAIL_RISK_NEXT : 0) | TAIL_LAST);
           if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 2);
           if (rc == TFX_OK) rc = launch_advance(h, t + 1, st, 1);
         } else {
@@ -161,7 +153,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   h->split_half = -1;
   st = user_st;
   if (rc != TFX_OK) return rc;
-  if (split && !envk) {
+  if (split) {
     n_pair /= 2;  // (both halves counted them)
     if (int jrc = guard.join()) return jrc;
   }
@@ -200,7 +192,7 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
       if (int rc = launch_move_tt<true>(h, t, st)) return rc;
       if (timed) HIPCHK(hipEventRecord(e[1], st));
       if (tail_usable(h)) {
-        if (int rc = launch_tail(h, t, st)) return rc;
+        if (int rc = launch_tail(h, t, st, false, t + 2 >= n_ticks ? TAIL_LAST : 0)) return rc;
         h->tail_ticks += 2;
       } else {
         if (int rc = launch_advance(h, t, st)) return rc;
@@ -237,22 +229,6 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
 
 // n_ticks ticks on the per-tick kernels, the env range in two halves on two streams where that pays
 int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
-  if (env_usable(h, n_ticks)) {
-    // all the ticks in ONE launch, a workgroup per env (tfx_env.hpp)
-    const bool timed = h->prof && h->ev_used < h->ev_ticks;
-    hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
-    if (timed) HIPCHK(hipEventRecord(e[0], st));
-    if (int rc = launch_env(h, n_ticks, st)) return rc;
-    if (timed) {
-      HIPCHK(hipEventRecord(e[1], st));
-      HIPCHK(hipEventRecord(e[2], st));
-      h->ev_weight[h->ev_used] = n_ticks;
-      ++h->ev_used;
-    }
-    h->env_ticks += n_ticks;
-    h->pair_ticks += 2 * (n_ticks / 2);
-    return TFX_OK;
-  }
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
     if (int rc = ensure_split(h, st)) return rc;

@@ -31,24 +31,28 @@
 
 namespace tfx {
 
+// k_tail's flags
+enum { TAIL_RISK_NEXT = 1, TAIL_LAST = 2 };
+
 // bytes of LDS the staged form needs for one env
 inline size_t tail_lds_bytes(int R, int I, bool het) {
-  return (size_t)R * (sizeof(int4) + 3 * sizeof(int) + (het ? sizeof(int) : 0)) + (size_t)2 * I * sizeof(int);
+  return (size_t)R * (sizeof(int4) + 3 * sizeof(int) + (het ? sizeof(int) : 0)) + (size_t)2 * I * sizeof(int) + (((size_t)R + 15) & ~(size_t)15);
 }
 
 // AGENT: inside an agent step (tfx_agent_step).  Envs that stand still are skipped by the phases themselves; envs k_risk
 // marked for this pair (env_risk == t + 1: their first tick could overflow, so the pass took them through ONE tick) get
 // the advance of tick t here and their whole second tick from the two restricted launches that follow
-// (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).  risk_next != 0: another pair follows in
+// (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).  flags & TAIL_RISK_NEXT: another pair follows in
 // the same decision - the last phase evaluates k_risk's bound for it (the state it needs is what advance(t + 1) has
 // just left in LDS), so only the first pair of a decision pays a k_risk launch.
+// flags & TAIL_LAST: the last pair of its call - the outputs only a caller can read are stored (edge_tile's full_out).
 // W: validate mode - the cars' side words travel along (edge_tile)
 // HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
 // from an LDS copy of the table
 template <bool GREEDY = false, bool AGENT = false, bool W = false, bool HET = false>
-__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const int risk_next) {
+__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const int flags) {
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
-  extern __shared__ int4 s_dyn[];  // rec[R] | leading[R] | lastcar[R] | tailx[R] | (HET: taila[R]) | lights[2 I]
+  extern __shared__ int4 s_dyn[];  // rec[R] | leading[R] | lastcar[R] | tailx[R] | (HET: taila[R]) | lights[2 I] | hb[R] bytes
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
   if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
@@ -58,12 +62,15 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
   const int per_env = d.I + (d.R - d.r);
   const int sp0 = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? (tick + 1) % d.spawn_period : 0;
   const int R = d.R;
+  const int risk_next = flags & TAIL_RISK_NEXT;
+  const bool full_out = (flags & TAIL_LAST) != 0;
   int4 *const s_rec = s_dyn;
   int *const s_ld = reinterpret_cast<int *>(s_rec + R);
   int *const s_lc = s_ld + R;
   float *const s_tx = reinterpret_cast<float *>(s_lc + R);
   int *const s_ta = reinterpret_cast<int *>(s_tx + R);
   int *const s_lt = s_ta + (HET ? R : 0);
+  uint8_t *const s_hb = reinterpret_cast<uint8_t *>(s_lt + 2 * d.I);
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
         s_lc[e] = d.lastcar[base + e];
         s_tx[e] = d.tailx[base + e];
         if (HET) s_ta[e] = d.taila[base + e];
+        s_hb[e] = d.hb[base + e];
       }
       const int *lt = d.lights + (size_t)env * d.lights_stride;
       for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) s_lt[i] = lt[i];
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
       dl.lastcar = s_lc - base;
       dl.tailx = s_tx - base;
       if (HET) dl.taila = s_ta - base;
+      dl.hb = s_hb - base;
       dl.lights = s_lt;
       dl.lights_stride = 0;
       __syncthreads();
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
     } else {
       __syncthreads();
       for (int g = wv; g < d.G; g += nwv)
-        my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(dl, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch);
+        my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(dl, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch, full_out);
       __syncthreads();
       for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick + 1, tidx + 1);
       if (AGENT && risk_next) {
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
     {
       __syncthreads();
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
-        d.rec[base + e] = s_rec[e];
+        d.hb[base + e] = s_hb[e];  // (the road records themselves are dead: the next pass writes new ones)
         d.leading[base + e] = s_ld[e];
         d.lastcar[base + e] = s_lc[e];
         d.tailx[base + e] = s_tx[e];

@@ -595,12 +595,6 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_tail_ticks(self.h, C.byref(n)))
         return int(n.value)
 
-    def env_ticks(self):
-        """Ticks run so far by k_env: one launch per call, a workgroup per env, ring words resident in LDS (tfx_env_ticks)."""
-        n = C.c_int64()
-        nat.check(self.lib.tfx_env_ticks(self.h, C.byref(n)))
-        return int(n.value)
-
     def split_ticks(self):
         """Ticks of step() calls that ran as two halves of the env range on two streams (tfx_split_ticks)."""
         n = C.c_int64()

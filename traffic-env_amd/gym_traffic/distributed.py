@@ -8,6 +8,8 @@ rank 0 - ONE gather per snapshot over RCCL/xGMI (backend "nccl") on a side strea
 overlap it, or over gloo on CPU tensors in tests.  Snapshots are double-buffered: starting snapshot
 k waits only for snapshot k-2 (the previous user of the same buffer), never for k-1.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -61,6 +63,8 @@ class RolloutGather(object):
         self.pending = [None] * self.DEPTH
         self.started = 0
         self.collectives = 0          # gathers issued (one per snapshot)
+        self._timing = []             # per gather: (start event, end event) on the side stream, or seconds on the host
+        self._host_s = 0.0
 
     def _buf(self, pin):
         t = torch.zeros((self.words,), dtype=torch.int32, device=self.stage_dev)
@@ -69,8 +73,21 @@ class RolloutGather(object):
     def _wait_slot(self, k):
         w = self.pending[k]
         if w is not None:
+            t0 = time.perf_counter()
             w.wait()
+            if not self._timing:
+                self._host_s += time.perf_counter() - t0      # (host-staged gathers: the time the caller spent in them)
             self.pending[k] = None
+
+    def ms_per_snapshot(self):
+        """Mean duration of one gather in milliseconds: on the side stream between the events around the collective
+        (RCCL), or the host time spent issuing and waiting for it (gloo); None before the first gather."""
+        if not self.collectives:
+            return None
+        self.wait()
+        if self._timing:
+            return sum(a.elapsed_time(b) for a, b in self._timing) / len(self._timing)
+        return self._host_s / self.collectives * 1e3
 
     def start(self, obs, rewards, done):
         """Snapshot the three tensors and start gathering them to `dst`; returns immediately.  Only
@@ -97,9 +114,19 @@ class RolloutGather(object):
             self.side.wait_stream(torch.cuda.current_stream(self.device))
             ctx = torch.cuda.stream(self.side)
         if self.collect:
+            timed_dev = self.side is not None and self.stage_dev.type != "cpu" and len(self._timing) < 256
+            t0 = time.perf_counter()
             with ctx:
+                if timed_dev:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.side)
                 self.pending[k] = dist.gather(snap, self.recv[k] if self.rank == self.dst else None,
                                               dst=self.dst, group=self.group, async_op=True)
+                if timed_dev:
+                    e1.record(self.side)
+                    self._timing.append((e0, e1))
+            if not timed_dev:
+                self._host_s += time.perf_counter() - t0
             self.collectives += 1
 
     def wait(self):

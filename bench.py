@@ -411,19 +411,6 @@ def main():
     # is 8 ms, and box to box and run to run the same binary moves by a few percent.
     run(a.warmup)
 
-    # Agent decisions, MEASURED: the fused 10-tick decision (Repeater + Remi, tfx_agent_step) under the same rules,
-    # before the timed regions (later the benchmark's entry roads run full, and an env that overflows in the first tick
-    # of a decision stands still for the rest of it - `if done: break` - which would time decisions that do nothing)
-    n_dec = 5
-    eng.agent_step(GATHER_EVERY, remi=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(n_dec):
-        adone = eng.agent_step(GATHER_EVERY, remi=True)[2]
-    fence()
-    dt_agent = time.perf_counter() - t0
-    agent_done = int(adone.sum().item())
-
     pair_ticks0, split_ticks0 = eng.pair_ticks(), eng.split_ticks()
     regions = []
     for _ in range(max(1, a.repeats)):
@@ -447,6 +434,25 @@ def main():
     prof = eng.profile_read()
     prof_updates = eng.vehicle_updates()
     eng.profile(0)
+
+    # Agent decisions, MEASURED: the fused 10-tick decision (Repeater + Remi, tfx_agent_step) under the same rules, on
+    # a second handle brought to the state the first timed region started from (prefill, settle ticks, warm-up): late in a
+    # long run the benchmark's entry roads run full, and an env that overflows in the first tick of a decision stands
+    # still for the rest of it (`if done: break`) - which would time decisions that do nothing
+    eng2 = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
+    for n in [50] * (settle // 50) + [settle % 50, a.warmup]:
+        if n:
+            eng2.step(n)
+    n_dec = 5
+    eng2.agent_step(GATHER_EVERY, remi=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(n_dec):
+        adone = eng2.agent_step(GATHER_EVERY, remi=True)[2]
+    fence()
+    dt_agent = time.perf_counter() - t0
+    agent_done = int(adone.sum().item())
+    del eng2
 
     red_dev = torch.device("cpu") if rehearsal else device
     tt = torch.tensor([r[0] for r in regions] + [dt_agent], dtype=torch.float64, device=red_dev)

@@ -57,8 +57,18 @@ struct Dev {
   // transposed layout: rows at the top of a road's column that hold no car (0..TFX_KP; see rec_hb) - a byte per road
   // of its own since round 4: the pass reads one byte instead of a 16-byte record, k_tail writes one back
   uint8_t *hb;
-  int4 *rec2;     // per road, two-tick pass only (tfx_move_tt.hpp): {bits of the tail's v after the first tick, waiting and
-                  //   detected counts of the second tick so far, bits of the tail's x after the second tick}
+  // per road, two-tick pass only (tfx_move_tt.hpp): what the pass hands to the edge work of the second tick, 12 bytes
+  // (round 3: one 16-byte record): {v of the tail after the first tick, x of the tail after the second} and the
+  // waiting (both ticks so far) | detected << 16 (second tick so far) counts
+  float2 *rec2f;
+  int *rec2c;
+  // A two-tick pass that k_tail follows (use_crec) writes its road record in 8 bytes instead of rec's 16 - {pops |
+  // cars on the road << 9 | table row of the tail << 18 | uncompacted << 24 | spawn overflows? << 25, bits of the tail's x}
+  // (crec_pack) - and the count of spawn overflows, when there are any, to ovf_cnt; k_tail expands it into its LDS copy
+  // of rec, so the phase code reads what it always read
+  int2 *crec;
+  int *ovf_cnt;
+  int use_crec;
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; the first TFX_KP = 2 cars that
   // left a road this tick wait in its outbox column outb[tile][j][64], j < KP - a road that pops more
   // stays uncompacted for the tick and its env takes the serial advance; the fake leader's x has no
@@ -74,8 +84,6 @@ struct Dev {
   // the current pair's
   int *env_risk;
   int risk_stride;  // words from one plane to the other (the whole handle's E, also inside the half of a split call)
-  int4 *exp_pad;    // TFX_EXP_PAD=n (timing experiments): k_tail writes n extra 16-byte words per road here
-  int exp_pad_n;
   int *risk_any;  // [2], one per plane of env_risk: == tick+1 when any env is marked for the pair starting at `tick`
   unsigned long long *veh;
   int *tickA, *tickB;
@@ -365,6 +373,15 @@ __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 // rec.w: cars on the road during the move (incl. this tick's arrivals) | table row of the last of them << 16
 __device__ __forceinline__ int rec_ntot(int rw) { return rw & 0xffff; }
 __device__ __forceinline__ int rec_taila(int rw) { return rw >> 16; }
+
+__device__ __forceinline__ int crec_pack(int kpop, int n_tot, int taila, bool unc, bool ovf) {
+  return kpop | (n_tot << 9) | (taila << 18) | (unc ? 1 << 24 : 0) | (ovf ? 1 << 25 : 0);
+}
+// the 16-byte road record from its 8-byte form (ovf_sp: the spawn overflows, read from ovf_cnt when bit 25 is set; the
+// head slot of rec.x is a ring-layout notion and stays 0)
+__device__ __forceinline__ int4 crec_expand(int2 c, int ovf_sp) {
+  return make_int4(c.x & 511, rec_y(ovf_sp, (c.x >> 24) & 1), c.y, ((c.x >> 9) & 511) | (((c.x >> 18) & 63) << 16));
+}
 
 // greedy.py:14-16: phase 1 iff the two N-S approaches hold more cars than the two E-W ones
 // (cars_on_roads().dot([1,1,-1,-1]) < 0) at intersection i of env

@@ -202,7 +202,10 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t ER = (size_t)d.E * R;
   size_t off = 0;
   const size_t o_rec = off;   off = align_up(off + ER * sizeof(int4), 256);
-  const size_t o_rec2 = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int4) : 0), 256);
+  const size_t o_rec2 = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(float2) : 0), 256);
+  const size_t o_rec2c = off; off = align_up(off + (d.layout == 1 ? ER * sizeof(int) : 0), 256);
+  const size_t o_crec = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int2) : 0), 256);
+  const size_t o_ovfc = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int) : 0), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
   const size_t o_risk = off;  off = align_up(off + 2 * (size_t)d.E * sizeof(int), 256);
@@ -230,7 +233,10 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   }
   char *base = (char *)h->dev_scratch;
   d.rec = (int4 *)(base + o_rec);
-  d.rec2 = (int4 *)(base + o_rec2);
+  d.rec2f = (float2 *)(base + o_rec2);
+  d.rec2c = (int *)(base + o_rec2c);
+  d.crec = d.layout == 1 ? (int2 *)(base + o_crec) : nullptr;
+  d.ovf_cnt = d.layout == 1 ? (int *)(base + o_ovfc) : nullptr;
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
   d.env_risk = (int *)(base + o_risk);
@@ -288,10 +294,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
     unsigned nbad = 1;
     if (hipMemcpy(&nbad, bad, sizeof nbad, hipMemcpyDeviceToHost) == hipSuccess && nbad == 0) d.fastmax = 1;
     (void)hipMemset(bad, 0, 8);
-  }
-  if (const char *pv = getenv("TFX_EXP_PAD")) {  // timing experiments only: extra bytes per road for k_tail to write
-    const int n = atoi(pv);
-    if (n > 0 && hipMalloc((void **)&d.exp_pad, (size_t)n * ER * sizeof(int4)) == hipSuccess) d.exp_pad_n = n;
   }
   d.action_mode = TFX_ACTION_CYCLE;
   d.action_period = 20;

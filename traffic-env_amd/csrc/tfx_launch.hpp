@@ -361,8 +361,9 @@ int edge_grid(tfx_handle h) {
 }
 
 // AGENT: inside an agent step; only_risky: the second tick of the envs k_risk sorted out of a pair
+// crec: k_tail follows this (two-tick) pass - the road records go out in their 8-byte form (Dev::crec)
 template <bool TWO, bool AGENT = false>
-int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
+int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, bool crec = false) {
   // Grid: 10 workgroups per CU, 6 of them resident at once.  Measured at cfg2 (ms per pass alone on the chip
   // / vehicle-updates per second of the split call, same box): 6 workgroups per CU - every one resident for the whole
   // launch - 0.741 / 5.22-5.26e11; 10-12 per CU 0.706-0.719 / 5.26e11; 24 per CU 0.682 / 5.15e11; one tile per
@@ -391,9 +392,11 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   if (grid < 1) grid = 1;
   const bool stagger = TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
-  if (h->d.het) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true, true>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
-  else if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
-  else hipLaunchKernelGGL((k_move_tt<TWO, AGENT, false>), dim3((unsigned)grid), dim3(256), 0, st, h->d, tidx, only_risky);
+  Dev dd = h->d;
+  dd.use_crec = (TWO && crec) ? 1 : 0;
+  if (h->d.het) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true, true>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
+  else if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
+  else hipLaunchKernelGGL((k_move_tt<TWO, AGENT, false>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
   HIPCHK(hipGetLastError());
   if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));
   if (stagger) h->split_first = false;
@@ -422,9 +425,13 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   if (d.trip_times) s.trip_times = d.trip_times + L * (size_t)d.trip_cap;
   if (d.n_trips) s.n_trips = d.n_trips + L;
   s.rec = d.rec + L * R;
-  s.rec2 = d.rec2 + L * R;
+  s.rec2f = d.rec2f + L * R;
+  if (d.crec) {
+    s.crec = d.crec + L * R;
+    s.ovf_cnt = d.ovf_cnt + L * R;
+  }
+  s.rec2c = d.rec2c + L * R;
   if (d.hb) s.hb = d.hb + L * R;
-  if (d.exp_pad) s.exp_pad = d.exp_pad + L * R;
   s.tailx = d.tailx + L * R;
   if (d.taila) s.taila = d.taila + L * R;
   if (d.spawn_arch) s.spawn_arch = d.spawn_arch + L * (size_t)d.n_entry * (size_t)d.spawn_arch_S;

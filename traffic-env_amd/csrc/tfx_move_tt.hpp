@@ -278,9 +278,17 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
       if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
     }
     if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
-    d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
-                          n_tot | (HET ? last_a << 16 : 0));
-    if (two) d.rec2[id] = make_int4(__float_as_int(y1v), n_wait + n_wait1, n_det1, __float_as_int(tail_z));
+    if (TWO && d.use_crec) {  // (k_tail follows: 8 bytes instead of 16)
+      d.crec[id] = make_int2(crec_pack(kpop, n_tot, HET ? last_a : 0, kpop > KP, p.ovf_sp > 0), __float_as_int(tail_x));
+      if (p.ovf_sp > 0) d.ovf_cnt[id] = p.ovf_sp;
+    } else {
+      d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),
+                            n_tot | (HET ? last_a << 16 : 0));
+    }
+    if (two) {
+      d.rec2f[id] = make_float2(y1v, tail_z);
+      d.rec2c[id] = (n_wait + n_wait1) | (n_det1 << 16);
+    }
     if (far || kpop > KP) d.env_flag[env] = tick + 1;
     if (hb) d.hb[id] = 0;  // (the column was written compacted)
     if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
@@ -394,7 +402,8 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   if (e < 0) return 0;
   const int id = env * d.R + e;
   const int4 rc = d.rec[id];    // the pass's record of the first tick
-  const int4 r2 = d.rec2[id];
+  const int r2c = d.rec2c[id];   // the road's waiting count of the first tick plus the second tick's so far | detected so far << 16
+  const float2 r2f = d.rec2f[id];  // the tail's v after the first tick, its x after the second
   const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, true, true);
   const int m0 = rec_ntot(rc.w) - rec_kpop(rc.x);  // survivors of the first tick: rows 0 .. m0-1 (row 0 = the head)
   const int n_old = p.n_old, n_tot = p.n_tot;
@@ -404,8 +413,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
   float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
-  // r2.y: the road's waiting count of the first tick plus the second tick's so far; r2.z: detected so far
-  int kpop = 0, n_wait = r2.y, n_det = r2.z;
+  int kpop = 0, n_wait = r2c & 0xffff, n_det = r2c >> 16;
   bool open = true, far = false;
   const int kq = C - 1 - p.ld;
   float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
@@ -462,8 +470,8 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     }
     if (m0 >= 2) {  // whoever queues behind the survivors follows the last one's tick-t state
       lx = __int_as_float(rc.z);
-      lv = __int_as_float(r2.x);
-      tail_x = __int_as_float(r2.w);
+      lv = r2f.x;
+      tail_x = r2f.y;
       if (HET) {
         last_a = rec_taila(rc.w);
         ll = arch[last_a * ARCH_W + AR_L];

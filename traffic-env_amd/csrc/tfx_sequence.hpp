@@ -126,7 +126,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         // (k_tail evaluates the bound for the pair that follows it: only the first pair pays a launch of its own)
         const bool tail = tail_usable(h);
         if (rc == TFX_OK && !(tail && t > 0)) rc = launch_risk(h, t, st);
-        if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st);
+        if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st, 0, tail);
         if (rc == TFX_OK && tail) {
           // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
           // (TAIL_LAST on every pair: an env that overflows stands still from there on, with what its last pair stored)
@@ -189,7 +189,7 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
       hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
       if (int rc = launch_inputs(h, st)) return rc;
       if (timed) HIPCHK(hipEventRecord(e[0], st));
-      if (int rc = launch_move_tt<true>(h, t, st)) return rc;
+      if (int rc = launch_move_tt<true>(h, t, st, 0, tail_usable(h))) return rc;
       if (timed) HIPCHK(hipEventRecord(e[1], st));
       if (tail_usable(h)) {
         if (int rc = launch_tail(h, t, st, false, t + 2 >= n_ticks ? TAIL_LAST : 0)) return rc;

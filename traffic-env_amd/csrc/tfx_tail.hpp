@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
     const size_t base = (size_t)env * R;
     {
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
-        s_rec[e] = d.rec[base + e];
+        {
+          const int2 c = d.crec[base + e];  // the pass's record in its 8-byte form
+          s_rec[e] = crec_expand(c, ((c.x >> 25) & 1) ? d.ovf_cnt[base + e] : 0);
+        }
         s_ld[e] = d.leading[base + e];
         s_lc[e] = d.lastcar[base + e];
         s_tx[e] = d.tailx[base + e];
@@ -136,7 +139,6 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
         d.lastcar[base + e] = s_lc[e];
         d.tailx[base + e] = s_tx[e];
         if (HET) d.taila[base + e] = s_ta[e];
-        for (int k = 0; k < d.exp_pad_n; ++k) d.exp_pad[(size_t)k * d.E * R + base + e] = s_rec[e];
       }
       int *lt = d.lights + (size_t)env * d.lights_stride;
       for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) lt[i] = s_lt[i];

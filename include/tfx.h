@@ -260,6 +260,11 @@ int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
  * second tick's inputs are produced on the device in between (tfx_set_poisson, TFX_ACTION_GREEDY).  TFX_TAIL=0
  * turns it off, TFX_TAIL=2 forces it at any batch size; results are bit-identical. */
 int tfx_tail_ticks(tfx_handle h, int64_t *ticks);
+/* Inside tfx_agent_step a pair of ticks runs as ONE pass over the cars only for envs in which the pair's first tick
+ * provably cannot overflow a ring (a bound on how far a car can move, csrc/tfx_move_tt.hpp risk_lane); the others take
+ * the pair one tick at a time, which is what `if done: break` (traffic_test.py:55) needs.  pairs = env-pairs that took
+ * that slower, equally exact path since tfx_create (synchronises the stream). */
+int tfx_slow_pairs(tfx_handle h, uint64_t *pairs, void *stream);
 /* Ticks of tfx_step calls that ran as two halves of the env range, the second half on a stream the handle owns
  * (forked from and joined to the caller's stream with events, so the call keeps its stream semantics): the
  * latency-bound per-road launch of one half then runs under the other half's pass over the cars.  Used for calls

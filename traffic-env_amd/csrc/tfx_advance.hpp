@@ -211,19 +211,14 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
 }
 
 // GREEDY: the on-device greedy controller is on (the kernels without it keep its loads out of their registers)
-// only_risky (agent steps behind k_tail): nothing but the envs k_risk sorted out of the pair that began at tick - 1 -
-// the advance of their second tick; returns at once when there is none
 template <bool TL, bool HET = false, bool GREEDY = false>
-__global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx, const int only_risky) {
-  // (behind k_tail the clock already stands past the pair: the tick is tickA - 1, whatever the restricted pass left in tickB)
-  const int tick = only_risky ? *d.tickA - 1 : *d.tickB;
-  if (only_risky && risk_any_word(d, tidx) != tick) return;
+__global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
+  const int tick = *d.tickB;
   const int per_env = d.I + (d.R - d.r);
   const long total = (long)d.E * per_env;
   for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
-    if (only_risky && risk_word(d, env, tidx) != tick) continue;
     if (gid == 0) *d.tickA = tick + 1;
     advance_item<TL, HET, GREEDY>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
   }

@@ -62,13 +62,12 @@ struct Dev {
   // waiting (both ticks so far) | detected << 16 (second tick so far) counts
   float2 *rec2f;
   int *rec2c;
-  // A two-tick pass that k_tail follows (use_crec) writes its road record in 8 bytes instead of rec's 16 - {pops |
+  // A two-tick pass that k_tail follows (its CREC form) writes its road record in 8 bytes instead of rec's 16 - {pops |
   // cars on the road << 9 | table row of the tail << 18 | uncompacted << 24 | spawn overflows? << 25, bits of the tail's x}
   // (crec_pack) - and the count of spawn overflows, when there are any, to ovf_cnt; k_tail expands it into its LDS copy
   // of rec, so the phase code reads what it always read
   int2 *crec;
   int *ovf_cnt;
-  int use_crec;
   // transposed layout only (tfx_config.layout = 1): xv is T[tile][k][64]; the first TFX_KP = 2 cars that
   // left a road this tick wait in its outbox column outb[tile][j][64], j < KP - a road that pops more
   // stays uncompacted for the tick and its env takes the serial advance; the fake leader's x has no
@@ -86,6 +85,7 @@ struct Dev {
   int risk_stride;  // words from one plane to the other (the whole handle's E, also inside the half of a split call)
   int *risk_any;  // [2], one per plane of env_risk: == tick+1 when any env is marked for the pair starting at `tick`
   unsigned long long *veh;
+  unsigned long long *slow_pairs;  // env-pairs of agent steps that k_tail took one tick at a time (tfx_slow_pairs)
   int *tickA, *tickB;
   // per-tick inputs
   const int *action;

@@ -270,6 +270,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.tickB = (int *)(base + o_misc + 32);
   d.agent_first = (const int *)(base + o_misc + 48);
   d.risk_any = (int *)(base + o_misc + 56);   // two words
+  d.slow_pairs = (unsigned long long *)(base + o_misc + 88);
   h->tick2 = (int *)(base + o_misc + 64);     // tickA, tickB, risk_any[2] of the second half
   // reciprocal division is used only if it is exact for this handle's constants on the whole
   // admitted numerator domain (2 x ~2^31 quotients, a few milliseconds; TFX_FASTDIV=0 disables)
@@ -738,6 +739,16 @@ int tfx_pair_ticks(tfx_handle h, int64_t *ticks) {
 int tfx_tail_ticks(tfx_handle h, int64_t *ticks) {
   if (int rc = check_handle(h, false)) return rc;
   if (ticks) *ticks = h->tail_ticks;
+  return TFX_OK;
+}
+
+int tfx_slow_pairs(tfx_handle h, uint64_t *pairs, void *stream) {
+  if (int rc = check_handle(h, false)) return rc;
+  if (!pairs) return fail(TFX_EINVAL, "pairs is null");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long v = 0;
+  HIPCHK(hipMemcpy(&v, h->d.slow_pairs, sizeof v, hipMemcpyDeviceToHost));
+  *pairs = (uint64_t)v;
   return TFX_OK;
 }
 

@@ -299,7 +299,7 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   return TFX_OK;
 }
 
-int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
+int launch_advance(tfx_handle h, int tidx, hipStream_t st) {
   const Dev &d = h->d;
   if (h->grid_adv == 0) {
     // no more blocks than are resident at once (k_advance<true> holds 5 per CU): with 8 per CU launched the
@@ -318,14 +318,14 @@ int launch_advance(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0) {
   TFX_INJECT(h);
   const bool g = h->greedy;
   if (h->het) {
-    if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
-    else hipLaunchKernelGGL((k_advance<true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    if (g) hipLaunchKernelGGL((k_advance<true, true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL((k_advance<true, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
   } else if (d.layout == 1) {
-    if (g) hipLaunchKernelGGL((k_advance<true, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
-    else hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    if (g) hipLaunchKernelGGL((k_advance<true, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL(k_advance<true>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
   } else {
-    if (g) hipLaunchKernelGGL((k_advance<false, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
-    else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx, only_risky);
+    if (g) hipLaunchKernelGGL((k_advance<false, false, true>), dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
+    else hipLaunchKernelGGL(k_advance<false>, dim3(h->grid_adv), dim3(256), 0, st, d, tidx);
   }
   HIPCHK(hipGetLastError());
   return TFX_OK;
@@ -392,11 +392,15 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   if (grid < 1) grid = 1;
   const bool stagger = TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
-  Dev dd = h->d;
-  dd.use_crec = (TWO && crec) ? 1 : 0;
-  if (h->d.het) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true, true>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
-  else if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
-  else hipLaunchKernelGGL((k_move_tt<TWO, AGENT, false>), dim3((unsigned)grid), dim3(256), 0, st, dd, tidx, only_risky);
+  const dim3 g((unsigned)grid), b(256);
+  if (TWO && crec) {  // (k_tail follows)
+    constexpr bool CR = TWO;
+    if (h->d.het) hipLaunchKernelGGL((k_move_tt<CR, AGENT, true, true, CR>), g, b, 0, st, h->d, tidx, only_risky);
+    else if (h->d.w) hipLaunchKernelGGL((k_move_tt<CR, AGENT, true, false, CR>), g, b, 0, st, h->d, tidx, only_risky);
+    else hipLaunchKernelGGL((k_move_tt<CR, AGENT, false, false, CR>), g, b, 0, st, h->d, tidx, only_risky);
+  } else if (h->d.het) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true, true>), g, b, 0, st, h->d, tidx, only_risky);
+  else if (h->d.w) hipLaunchKernelGGL((k_move_tt<TWO, AGENT, true>), g, b, 0, st, h->d, tidx, only_risky);
+  else hipLaunchKernelGGL((k_move_tt<TWO, AGENT, false>), g, b, 0, st, h->d, tidx, only_risky);
   HIPCHK(hipGetLastError());
   if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));
   if (stagger) h->split_first = false;
@@ -503,7 +507,9 @@ int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int flags) {
   }
   if (h->size_only) return TFX_OK;
   TFX_INJECT(h);
-  const bool halves = h->split_half >= 0;
+  // (inside agent steps the whole-size workgroups win in the halves as well: measured at cfg2, 128 / 192 / 256 lanes:
+  // plain calls 0.399 / 0.406 / 0.414 ms per tick, fused decisions 4.72 / 4.63 / 4.51 ms)
+  const bool halves = h->split_half >= 0 && !AGENT;
   const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? h->tail_threads_half : h->tail_threads);
   hipLaunchKernelGGL(kern, g, b, lds, st, h->d, tidx, flags);
   HIPCHK(hipGetLastError());

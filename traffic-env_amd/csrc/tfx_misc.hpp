@@ -275,13 +275,6 @@ __global__ void k_greedy(const Dev d, int *action, int spacing) {
   }
 }
 
-// done flags of an agent step: overflow in any tick since the step began
-__global__ void k_done_since(const Dev d, uint8_t *out, const int *first) {
-  const int f = *first;
-  for (int env = blockIdx.x * blockDim.x + threadIdx.x; env < d.E; env += gridDim.x * blockDim.x)
-    out[env] = d.done_tick[env] > f ? 1 : 0;
-}
-
 // start of a fused agent step: remember the tick it starts at (env_frozen compares against it)
 __global__ void k_agent_begin(const Dev d, int *first) { *first = *d.tickA; }
 
@@ -291,24 +284,52 @@ __global__ void k_clock_copy(const int *tickA, const int *tickB, int *clock2) {
   clock2[1] = *tickB;
 }
 
-// Repeater's observation (traffic_test.py:48-53): [sum of passed | last detected | elapsed/100 *
-// (2*phase - 1)] as float32, from the int obs the ticks left behind (passed accumulated in place).
-__global__ void k_agent_obs(const Dev d, float *aobs) {
+// The end of a fused decision in ONE launch (round 3: four): remi's reward per intersection (traffic_env.py:64-78, as
+// k_remi) or the summed rewards as they stand, copied to areward; Repeater's observation (traffic_test.py:48-53): [sum
+// of passed | last detected | elapsed/100 * (2*phase - 1)] as float32, from the int obs the ticks left behind (passed
+// accumulated in place); the done flags: overflow in any tick since the decision began.  No element depends on another's.
+__global__ void k_agent_tail(const Dev d, const int remi, float *aobs, float *areward, uint8_t *adone, const int *first) {
   const int alen = 2 * d.r + d.I;
-  const long total = (long)d.E * alen;
+  const long n_int = (long)d.E * d.I, total = (long)d.E * alen;
+  const int f = *first;
   for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-    const int env = (int)(g / alen);
-    const int k = (int)(g - (long)env * alen);
-    const int *ob = d.obs + (size_t)env * d.obs_len;
-    float v;
-    if (k < 2 * d.r) {
-      v = (float)ob[k];
-    } else {
-      const int i = k - 2 * d.r;
-      const int mult = 2 * ob[2 * d.r + i] - 1;
-      v = (float)((double)ob[2 * d.r + d.I + i] / 100.0 * (double)mult);
+    if (g < n_int) {
+      float rw;
+      if (remi) {
+        const int env = (int)(g / d.I);
+        const int i = (int)(g - (long)env * d.I);
+        const int cur = d.obs[(size_t)env * d.obs_len + 2 * d.r + i];
+        const bool pd = d.passed_dst[g] != 0;
+        rw = 0.0f;
+        for (int dir = 0; dir < 4; ++dir) {
+          const bool green = ((dir < 2) ? 1 : 0) != cur;
+          int *wp = d.waiting + (size_t)env * d.r + dir * d.I + i;
+          const bool waiting = *wp > 0;
+          if (waiting && !green && !pd) rw -= 0.5f;
+          else if (pd && green && !waiting) rw += 0.5f;
+          *wp = 0;
+        }
+        d.rewards[g] = rw;
+        d.passed_dst[g] = 0;
+      } else {
+        rw = d.rewards[g];
+      }
+      if (areward) areward[g] = rw;
     }
-    aobs[g] = v;
+    if (adone && g < d.E) adone[g] = d.done_tick[g] > f ? 1 : 0;
+    if (aobs) {
+      const int env = (int)(g / alen);
+      const int k = (int)(g - (long)env * alen);
+      const int *ob = d.obs + (size_t)env * d.obs_len;
+      float v;
+      if (k < 2 * d.r) {
+        v = (float)ob[k];
+      } else {
+        const int i = k - 2 * d.r;
+        v = (float)((double)ob[2 * d.r + d.I + i] / 100.0 * (double)(2 * ob[2 * d.r + i] - 1));
+      }
+      aobs[g] = v;
+    }
   }
 }
 

@@ -47,8 +47,8 @@ namespace tfx {
 
 // AGENT: inside an agent step - frozen envs are skipped, `passed` accumulates over the step, tiles of risky
 // envs (env_risk == tick + 1) take the one-tick form; only_risky: nothing but the tiles of envs marked risky
-// for the pair that began one tick earlier (the second tick of those envs); only_risky = 2: the same behind k_tail,
-// which has already moved the clock past the pair (the tick is tickA - 1)
+// for the pair that began one tick earlier (the second tick of those envs, where k_edge finishes the pairs: behind
+// k_tail that tick runs inside k_tail itself)
 #ifndef TT_P
 #define TT_P 4
 #endif
@@ -70,17 +70,23 @@ namespace tfx {
 // One tile (64 roads of one env, lane = road) of a pass: every car through tick `tick` and - `two` - all but the roads'
 // heads and joiners through tick + 1 as well.  Returns the lane's vehicle-updates of tick `tick`.  Reads and writes the
 // ring words (leading, lastcar, tailx, rec, the light words) through `d`.
-template <bool TWO, bool AGENT, bool W, bool HET>
+// CREC: k_tail follows this (two-tick) pass - the road record goes out in its 8-byte form (Dev::crec)
+template <bool TWO, bool AGENT, bool W, bool HET, bool CREC = false>
 __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const int env, const int lane, const int tick,
-                                            const int tick_sp, const int tidx, const bool two, const float *s_arch) {
+                                            const int tick_sp, const int tidx, const bool two, const float *s_arch,
+                                            const bool skip = false) {
   constexpr int P = TT_P;
   const int C = d.C;
   const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
   const bool valid = e_slot >= 0;
   const int e = valid ? e_slot : 0;
   const int id = env * d.R + e;
-  const bool run = valid && !(AGENT && env_frozen(d, env, tick));
-  const int hb = run ? d.hb[id] : 0;  // rows the second tick of the last pair left empty at the top of the column
+  // (no early exit for a tile that is skipped or stands still: the words that say so are loaded side by side with the
+  // rest of the prologue instead of ahead of it - an early `continue` cost the agent pass 9 % of its time)
+  const int hb0 = valid ? d.hb[id] : 0;  // rows the second tick of the last pair left empty at the top of the column
+  const bool run = valid && !skip && !(AGENT && env_frozen(d, env, tick));
+  const int hb = run ? hb0 : 0;
+  if (hb) d.hb[id] = 0;               // (this walk writes the column compacted; nobody else reads the byte meanwhile)
   const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
   const int n_old = run ? p.n_old : 0;
   const int n_sp = run ? p.n_tot - p.n_old : 0;
@@ -273,12 +279,13 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
         if (!two) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
         ob[d.r + e] = n_det;
       }
-      if (AGENT) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;  // accumulates over the agent step
+      // accumulates over the agent step (a pair: edge_tile adds both ticks' pops at once)
+      if (AGENT && !two) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;
       else if (!two) ob[e] = kpop;  // (a pair: overwritten by the second tick before anyone reads it)
       if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
     }
     if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
-    if (TWO && d.use_crec) {  // (k_tail follows: 8 bytes instead of 16)
+    if (TWO && CREC) {  // (k_tail follows: 8 bytes instead of 16)
       d.crec[id] = make_int2(crec_pack(kpop, n_tot, HET ? last_a : 0, kpop > KP, p.ovf_sp > 0), __float_as_int(tail_x));
       if (p.ovf_sp > 0) d.ovf_cnt[id] = p.ovf_sp;
     } else {
@@ -290,21 +297,21 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
       d.rec2c[id] = (n_wait + n_wait1) | (n_det1 << 16);
     }
     if (far || kpop > KP) d.env_flag[env] = tick + 1;
-    if (hb) d.hb[id] = 0;  // (the column was written compacted)
     if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
     return n_tot;
   }
   return 0;
 }
 
-template <bool TWO, bool AGENT = false, bool W = false, bool HET = false>
+template <bool TWO, bool AGENT = false, bool W = false, bool HET = false, bool CREC = false>
 __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
+  static_assert(!CREC || TWO, "only a two-tick pass is followed by k_tail");
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
   if (HET) load_arch(d, s_arch);
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tick = *d.tickA - ((AGENT && only_risky == 2) ? 1 : 0);
+  const int tick = *d.tickA;
   const long tiles = (long)d.E * d.G;
   const long nw = (long)gridDim.x * 4;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
@@ -316,12 +323,17 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
   for (long tile = (long)blockIdx.x * 4 + wv; tile < tiles; tile += nw) {
     const int env = (int)(tile / d.G);  // a tile never straddles envs
     if (AGENT && only_risky && risk_word(d, env, tidx) != tick) continue;
-    // this tile goes through two ticks (wave-uniform)
-    const bool two = TWO && !(AGENT && risk_word(d, env, tidx) == tick + 1);
+    // the envs k_risk sorted out of this pair (their first tick could overflow).  Where k_tail follows, it takes them
+    // through both ticks itself, one at a time, and the pass leaves their tiles alone - every tile it does walk goes
+    // through two ticks, known at compile time.  Otherwise their tiles take the one-tick form here (wave-uniform) and
+    // a restricted launch brings the second tick.
+    const bool sorted_out = AGENT && TWO && risk_word(d, env, tidx) == tick + 1;
+    const bool two = TWO && (CREC || !sorted_out);
     // (a stamp left by an earlier run at the same tick number - the clock can be set back - is honoured all the
     // way: this pass takes the tile one tick at a time, k_edge skips it, and the restricted launch must come)
     if (AGENT && TWO && !two && lane == 0) risk_any_word(d, tidx) = tick + 1;
-    my_updates += (unsigned long long)move_tt_tile<TWO, AGENT, W, HET>(d, tile, env, lane, tick, tick_sp, tidx, two, s_arch);
+    my_updates += (unsigned long long)move_tt_tile<TWO, AGENT, W, HET, CREC>(d, tile, env, lane, tick, tick_sp, tidx, two, s_arch,
+                                                                            CREC && sorted_out);
   }
 
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
@@ -511,7 +523,8 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     int *ob = d.obs + (size_t)env * d.obs_len;
     if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
     if (n_tot > 0) ob[d.r + e] = n_det;
-    if (AGENT) ob[e] += kpop;
+    // (agent step: `passed` accumulates - this tick's pops and the pass's of the tick before; the first pair starts it)
+    if (AGENT) ob[e] = (tidx > 1 ? ob[e] : 0) + rec_kpop(rc.x) + kpop;
     else if (full_out) ob[e] = kpop;
     if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
   }

@@ -128,11 +128,9 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         if (rc == TFX_OK && !(tail && t > 0)) rc = launch_risk(h, t, st);
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st, 0, tail);
         if (rc == TFX_OK && tail) {
-          // the rest of the pair in one launch; the envs k_risk sorted out get their second tick behind it
+          // the rest of the pair in one launch (the envs k_risk sorted out get their second tick inside it)
           // (TAIL_LAST on every pair: an env that overflows stands still from there on, with what its last pair stored)
           rc = launch_tail(h, t, st, true, (t + 3 < n_ticks ? TAIL_RISK_NEXT : 0) | TAIL_LAST);
-          if (rc == TFX_OK) rc = launch_move_tt<false, true>(h, t + 1, st, 2);
-          if (rc == TFX_OK) rc = launch_advance(h, t + 1, st, 1);
         } else {
           if (rc == TFX_OK) rc = launch_advance(h, t, st);
           if (rc == TFX_OK) rc = launch_inputs(h, st);
@@ -159,18 +157,9 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
   }
   d.agent_mode = guard.keep.agent_mode;  // the tail kernels below run outside the step's tick loop
   d.accum_rewards = guard.keep.accum_rewards;
-  if (remi) {
-    hipLaunchKernelGGL(k_remi, dim3(grid_for((long)d.E * d.I, h->n_cu)), dim3(256), 0, st, d);
-    HIPCHK(hipGetLastError());
-  }
-  if (aobs) {
-    hipLaunchKernelGGL(k_agent_obs, dim3(grid_for((long)d.E * (2 * d.r + d.I), h->n_cu)), dim3(256), 0, st, d, aobs);
-    HIPCHK(hipGetLastError());
-  }
-  if (areward)
-    HIPCHK(hipMemcpyAsync(areward, d.rewards, (size_t)d.E * d.I * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (adone) {
-    hipLaunchKernelGGL(k_done_since, dim3(grid_for(d.E, h->n_cu)), dim3(256), 0, st, d, adone, d.agent_first);
+  if (remi || aobs || areward || adone) {
+    hipLaunchKernelGGL(k_agent_tail, dim3(grid_for((long)d.E * (2 * d.r + d.I), h->n_cu)), dim3(256), 0, st, d, remi, aobs,
+                       areward, adone, d.agent_first);
     HIPCHK(hipGetLastError());
   }
   return TFX_OK;

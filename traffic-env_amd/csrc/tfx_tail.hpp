@@ -40,17 +40,18 @@ inline size_t tail_lds_bytes(int R, int I, bool het) {
 }
 
 // AGENT: inside an agent step (tfx_agent_step).  Envs that stand still are skipped by the phases themselves; envs k_risk
-// marked for this pair (env_risk == t + 1: their first tick could overflow, so the pass took them through ONE tick) get
-// the advance of tick t here and their whole second tick from the two restricted launches that follow
-// (k_move_tt<false, true> with only_risky = 2, k_advance with only_risky = 1).  flags & TAIL_RISK_NEXT: another pair follows in
+// marked for this pair (env_risk == t + 1: their first tick could overflow, so the pass left them alone) get BOTH ticks
+// here, one at a time, from this same workgroup.  flags & TAIL_RISK_NEXT: another pair follows in
 // the same decision - the last phase evaluates k_risk's bound for it (the state it needs is what advance(t + 1) has
 // just left in LDS), so only the first pair of a decision pays a k_risk launch.
 // flags & TAIL_LAST: the last pair of its call - the outputs only a caller can read are stored (edge_tile's full_out).
 // W: validate mode - the cars' side words travel along (edge_tile)
 // HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
 // from an LDS copy of the table
+// As many registers as a wavefront of the pass it runs beside (TT_ATTR: 80, with the side-word plane 128): its
+// wavefronts then fit the slots the pass's leave.
 template <bool GREEDY = false, bool AGENT = false, bool W = false, bool HET = false>
-__global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const int flags) {
+__global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int tidx, const int flags) {
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
   extern __shared__ int4 s_dyn[];  // rec[R] | leading[R] | lastcar[R] | tailx[R] | (HET: taila[R]) | lights[2 I] | hb[R] bytes
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
@@ -77,11 +78,12 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
     Dev dl = d;
     const size_t base = (size_t)env * R;
     {
+      // (Tried: the loads of 2 - 4 roads per lane in flight at once.  The kernel must stay within the registers of ONE
+      // wavefront of the pass - 80 - to take the slots the other half's pass frees one for one: unrolled four times it
+      // needed 112 and the cfg2 tick went from 0.399 to 0.425 ms; within 80 registers no unrolling changed the tick.)
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
-        {
-          const int2 c = d.crec[base + e];  // the pass's record in its 8-byte form
-          s_rec[e] = crec_expand(c, ((c.x >> 25) & 1) ? d.ovf_cnt[base + e] : 0);
-        }
+        const int2 c = d.crec[base + e];  // the pass's record in its 8-byte form
+        s_rec[e] = crec_expand(c, ((c.x >> 25) & 1) ? d.ovf_cnt[base + e] : 0);
         s_ld[e] = d.leading[base + e];
         s_lc[e] = d.lastcar[base + e];
         s_tx[e] = d.tailx[base + e];
@@ -101,34 +103,40 @@ __global__ __launch_bounds__(256) void k_tail(const Dev d, const int tidx, const
       dl.lights_stride = 0;
       __syncthreads();
     }
-    for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick, tidx);
-    // (workgroup-uniform: the envs k_risk sorted out get their second tick from the launches behind this one)
+    // (workgroup-uniform) an env k_risk sorted out of this pair: its first tick could overflow
     const bool sorted_out = AGENT && risk_word(d, env, tidx) == tick + 1;
-    if (sorted_out) {
-      // their second tick is still to come (the launches behind this one): no bound can be taken yet, so they take
-      // the next pair one tick at a time as well
-      if (risk_next && threadIdx.x == 0) {
-        risk_word(d, env, tidx + 2) = tick + 3;
-        risk_any_word(d, tidx + 2) = tick + 3;
+    if (AGENT && sorted_out) {
+      // The pass left this env's tiles alone.  Both of its ticks run here, one at a time - the one-tick pass over the
+      // env's tiles by this workgroup's wavefronts, then its advance, twice.  An env that does overflow in tick t stands
+      // still from there on (move_tt_tile and advance_item skip a frozen env: `if done: break`, traffic_test.py:55).
+      // (Round 3 gave these envs the one-tick form in the pass and two restricted launches behind every k_tail - ten
+      // launches per decision and half, all returning at once at the benchmark's density.)
+      if (threadIdx.x == 0) atomicAdd(d.slow_pairs, 1ull);
+      for (int u = 0; u < 2; ++u) {
+        const int spu = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? (tick + u) % d.spawn_period : 0;
+        if (u) __syncthreads();
+        for (int g = wv; g < d.G; g += nwv)
+          my_updates += (unsigned long long)move_tt_tile<false, AGENT, W, HET>(dl, (long)env * d.G + g, env, lane, tick + u, spu, tidx + u, false, s_arch);
+        __syncthreads();
+        for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick + u, tidx + u);
       }
     } else {
+      for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick, tidx);
       __syncthreads();
       for (int g = wv; g < d.G; g += nwv)
         my_updates += (unsigned long long)edge_tile<AGENT, W, HET>(dl, (long)env * d.G + g, env, lane, tick + 1, sp0, tidx + 1, s_arch, full_out);
       __syncthreads();
       for (int s = threadIdx.x; s < per_env; s += blockDim.x) advance_item<true, HET, GREEDY, W>(dl, env, s, tick + 1, tidx + 1);
-      if (AGENT && risk_next) {
-        __syncthreads();
-        const int t2 = tick + 2;
-        if (!env_frozen(d, env, t2)) {
-          const int sp2 = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? t2 % d.spawn_period : 0;
-          bool risky = false;
-          for (int g = wv; g < d.G; g += nwv) risky = risk_lane(dl, (long)env * d.G + g, env, lane, t2, sp2, tidx + 2) || risky;
-          if (__builtin_amdgcn_ballot_w64(risky) != 0ull && lane == 0) {
-            risk_word(d, env, tidx + 2) = t2 + 1;
-            risk_any_word(d, tidx + 2) = t2 + 1;
-          }
-        }
+    }
+    if (AGENT && risk_next) {
+      // k_risk's bound for the pair that follows, on the state advance(t + 1) has just left
+      __syncthreads();
+      const int t2 = tick + 2;
+      if (!env_frozen(d, env, t2)) {
+        const int sp2 = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? t2 % d.spawn_period : 0;
+        bool risky = false;
+        for (int g = wv; g < d.G; g += nwv) risky = risk_lane(dl, (long)env * d.G + g, env, lane, t2, sp2, tidx + 2) || risky;
+        if (__builtin_amdgcn_ballot_w64(risky) != 0ull && lane == 0) risk_word(d, env, tidx + 2) = t2 + 1;
       }
     }
     {

@@ -77,6 +77,7 @@ _PROTOS = {
     "tfx_fused_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tfx_pair_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_tail_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "tfx_slow_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "tfx_split_ticks": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "tfx_step_kernel": (C.c_char_p, [C.c_void_p]),
     "tfx_debug_fail_after": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -595,6 +595,12 @@ class TfxEngine(object):
         nat.check(self.lib.tfx_tail_ticks(self.h, C.byref(n)))
         return int(n.value)
 
+    def slow_pairs(self):
+        """Env-pairs of fused decisions that ran one tick at a time because the first tick could overflow (tfx_slow_pairs)."""
+        n = C.c_uint64()
+        nat.check(self.lib.tfx_slow_pairs(self.h, C.byref(n), self._stream()))
+        return int(n.value)
+
     def split_ticks(self):
         """Ticks of step() calls that ran as two halves of the env range on two streams (tfx_split_ticks)."""
         n = C.c_int64()

@@ -103,9 +103,10 @@ int launch_move_t(tfx_handle h, int tidx, hipStream_t st) {
     }
     if (cap <= 32) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<8>); }
     if (cap <= 64) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16>); }
-    // long roads on a launch of at most ~two tiles per CU: eight segments of 16 cars instead of four of 32
-    // (cfg4 x 1 env closed loop: 38.4 -> 28.6 us per tick)
-    if (cap <= 128 && cap > 64 && tiles <= (long)h->n_cu * 2) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<16, false, 8>, 512); }
+    // long roads on a launch of at most ~two tiles per CU: sixteen segments of 8 cars instead of four of 32
+    // (cfg4 x 1 env closed loop, eight of 16: 38.4 -> 28.6 us per tick)
+    // (sixteen of 8: 29.6 -> 28.8 us per tick at one env, 39.2 -> 37.7 at two - what is left is the launches' own latency)
+    if (cap <= 128 && cap > 64 && tiles <= (long)h->n_cu * 2) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<8, false, 16>, 1024); }
     if (cap <= 128) { h->step_kernel = "k_move_ts"; return gs(k_move_ts<32>); }
     { h->step_kernel = "k_move_ts"; return gs(k_move_ts<64>); }
   }

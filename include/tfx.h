@@ -109,8 +109,10 @@ typedef struct tfx_config {
    * table is ignored.  n_archetypes in 2..TFX_MAX_ARCH, or one row whose delta is not 4: "heterogeneous cars" -
    * every car carries the row it was spawned from through handoffs; needs layout = 1 and planes = 3 (the per-car
    * side word then holds (spawn tick mod 2^24) << 6 | row as integer bits; the envs never run LDS-resident), and takes the rows of spawned
-   * cars from tfx_set_spawn_archetypes.  delta must be an integer in 1..8: (v/v0)**delta is the binary64 product
-   * chain of oracle/idm_oracle.c powi_cr rounded once (for 4: the same value as the single-archetype path).
+   * cars from tfx_set_spawn_archetypes.  (v/v0)**delta: for an integer delta in 1..8 the binary64 product chain of
+   * oracle/idm_oracle.c powi_cr rounded once (for 4: the same value as the single-archetype path); for any other delta
+   * in (0, 64] the binary64 log2 / exp2 sequence of include/tfx_pow.h rounded once - both shared bit for bit with the
+   * oracle, both within 1 ulp of NumPy's float32 power, which is what the reference runs (traffic_env.py:56).
    * Row layout: v (spawn speed), l, a, delta, v0, b, T, s0. */
   int32_t n_archetypes;
   float arch[TFX_MAX_ARCH][8];

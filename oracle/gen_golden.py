@@ -70,6 +70,9 @@ scen("g2x2_three_archetypes", seed=7, T=300, lcps=0.25,
      archetypes=[[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 4, 10.0, 4, 2.5, 2], [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1]])
 scen("g3x3_two_archetypes_c10", m=3, n=3, C=10, seed=8, T=300, lcps=0.2,
      archetypes=[[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 4, 10.0, 4, 2.5, 2]])
+# exponents that are no integers (the reference's `**` takes any float, traffic_env.py:56): delta = 2.5, 4 and 0.75
+scen("g2x2_archetypes_fractional_delta", seed=9, T=300, lcps=0.25,
+     archetypes=[[11.11, 4, 3, 2.5, 13.89, 6, 2, 1], [8.0, 8, 1.5, 4, 10.0, 4, 2.5, 2], [12.0, 3.5, 4, 0.75, 16.0, 7, 1.5, 1]])
 # config 5 itself for the first 130 ticks (integers only): 64x64, Poisson arrivals at the default rate
 scen("g64x64_c130_ints", m=64, n=64, L=800.0, C=130, seed=0, T=130, state_every=0)
 

@@ -26,6 +26,7 @@
  * Pinning: tests/test_oracle_golden.py checks this file against the golden vectors captured
  * from the reference itself (oracle/gen_golden.py).
  */
+#include "../include/tfx_pow.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -84,7 +85,8 @@ static inline float pow4_cr(float q) {
 /* (v/v0)**delta for the other integer exponents an archetype may carry (traffic_env.py:38 fixes 4; a user row may
  * not): binary exponentiation in binary64 - result = 1, base = q; while n: if n odd result *= base; base *= base;
  * n >>= 1 - rounded once to binary32.  For n = 4 that is (q*q)*(q*q), i.e. pow4_cr.  The HIP side runs the same
- * multiplies; exponents that are not integers in 1..8 are outside the shared contract (powf here, rejected there). */
+ * multiplies; any other exponent goes through tfx_pow_det (include/tfx_pow.h): one binary64 operation sequence that
+ * both sides compile, rounded once to binary32. */
 static inline float powi_cr(float q, int n) {
   double result = 1.0, base = (double)q;
   while (n) {
@@ -114,7 +116,7 @@ static void sim(const orc_cfg *c, orc_env *v, int e, int lo, int hi, float *nx, 
     const float delta = ST(v, c, e, DELTAI, j);
     const float qd = (delta == 4.0f) ? pow4_cr(q)
                      : (delta >= 1.0f && delta <= 8.0f && delta == (float)(int)delta) ? powi_cr(q, (int)delta)
-                                                                                     : powf(q, delta);
+                                                                                     : tfx_pow_det(q, delta);
     const float u = s_star / (s + c->eps);
     const float dv = ST(v, c, e, AI, j) * ((1.0f - qd) - u * u);
     const float dvr = dv * r;

@@ -95,15 +95,31 @@ def ulp_diff(a, b):
     return np.abs(ai - bi)
 
 
-def assert_floats_match_reference(x, v, gx, gv, a_max=3.0, rate=0.5, where=""):
+# single-archetype fixtures with a car beyond 1 ulp in v (teacher-forced, oracle vs reference)
+WIDER_V = {"g4x4_cfg1"}
+
+
+def assert_floats_match_reference(x, v, gx, gv, a_max=3.0, rate=0.5, where="", single_default_archetype=False):
     """The float tolerance of ONE teacher-forced tick against the reference, stated once.  The
-    reference's NumPy float32 `**` is a platform SIMD routine within 1 ulp of the correctly rounded power the contract
-    uses, and that is the only difference.  One ulp of q**delta (<= 2^-23 for values below 2) shifts
-    dv = a (1 - q**delta - u^2) by at most a 2^-23 and can flip the rounding of the two subtractions and of v + dv rate
-    by one ulp each at the scale of the result.  So: x within 1 ulp (its increment carries half of the speed's error
-    times rate, far below an ulp of a position); v within 2 ulp, or within a_max rate 2^-22 absolute (3.6e-7 m/s for
-    the default archetype) for slow cars, whose own ulp is smaller than the shift."""
-    assert ulp_diff(x, gx).max() <= 1, where
+    reference's NumPy float32 `**` is a platform SIMD routine within 1 ulp of the power the contract uses (the binary64
+    multiply chain for integer exponents, include/tfx_pow.h otherwise), and that is the only difference.  One ulp of
+    q**delta (<= 2^-23 for values below 2) shifts dv = a (1 - q**delta - u^2) by at most a 2^-23 and can flip the
+    rounding of the two subtractions and of v + dv rate by one ulp each at the scale of the result.  So:
+      x  within 1 ulp - of x itself, or of its increment dx = rate v + dv rate^2 / 2 where that is the larger of the two (a
+         car just behind x = 0: x_new = x_old + dx cancels, and one ulp of dx is several of the small sum; first seen on
+         g2x2_archetypes_fractional_delta, tick 144, on a delta = 4 car);
+      v  within 2 ulp, or within a_max rate 2^-22 absolute (3.6e-7 m/s for the default archetype) for slow cars, whose
+         own ulp is smaller than the shift.
+    single_default_archetype: the fixtures of the reference's one default row (delta = 4) hold v <= 1 ulp and keep that
+    bound (round-3 advisor: the wider bound only where a fixture needs it) - all of them but g4x4_cfg1, whose tick 231
+    has one car at 2 ulp (WIDER_V below)."""
+    gx32, gv32 = np.asarray(gx, np.float32), np.asarray(gv, np.float32)
+    dx_scale = np.maximum(np.abs(gx32), rate * (np.abs(gv32) + a_max * rate)).astype(np.float32)
+    okx = (ulp_diff(x, gx) <= 1) | (np.abs(np.asarray(x, np.float64) - np.asarray(gx, np.float64)) <= np.spacing(dx_scale))
+    assert okx.all(), (where, int(ulp_diff(x, gx).max()))
     dv = np.abs(np.asarray(v, np.float64) - np.asarray(gv, np.float64))
-    ok = (ulp_diff(v, gv) <= 2) | (dv <= a_max * rate * 2.0 ** -22)
+    if single_default_archetype and (not where or where[0] not in WIDER_V):
+        ok = ulp_diff(v, gv) <= 1
+    else:
+        ok = (ulp_diff(v, gv) <= 2) | (dv <= a_max * rate * 2.0 ** -22)
     assert ok.all(), (where, float(dv.max()), int(ulp_diff(v, gv).max()))

@@ -43,7 +43,8 @@ def _worker(rank, world, port, out_dir):
         g.generate_entrypoints(0)
         env = OracleEnv(m, n, L, C, g.dest, g.phases, g.nexts, n_envs=E)
         env.reset(np.zeros(env.I, np.int32))
-        gather = RolloutGather(E, env.obs.shape[1], env.I, "cpu")
+        sizes = [b - a for a, b in (shard_range(total, r, world) for r in range(world))]
+        gather = RolloutGather(E, env.obs.shape[1], env.I, "cpu", counts=sizes)
         snaps = []
         for t in range(30):
             ids = np.arange(lo, hi)                               # GLOBAL env ids drive the inputs
@@ -100,12 +101,14 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gather_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_gather_equals_single_process(world, tmp_path):
+    """2 ranks (3 + 3 envs) and 4 ranks (2 + 2 + 1 + 1: uneven shards, padded to the largest)"""
     port = free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
     snaps, updates = _single_process_reference()
-    assert float(z["t_max"][0]) == 2.0
+    assert float(z["t_max"][0]) == float(world)
     assert float(z["updates"][0]) == float(updates) and updates > 0
     for i, (obs, rew, done) in enumerate(snaps):
         assert np.array_equal(z["s%d_0" % i], obs)       # env-id order, sharding-independent
@@ -153,8 +156,9 @@ def _uneven_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_uneven_shards_one_collective_per_snapshot(tmp_path):
-    mp.spawn(_uneven_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world", [2, 4])
+def test_uneven_shards_one_collective_per_snapshot(world, tmp_path):
+    mp.spawn(_uneven_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "uneven.npz"))
     ids = np.arange(7)
     assert np.array_equal(z["obs"], np.repeat(ids[:, None], 6, 1) + 400)

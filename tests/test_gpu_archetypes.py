@@ -123,11 +123,11 @@ def test_archetype_runs_teacher_forced_vs_reference(name, golden_cache):
 def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
     """Random ring states (wrapped, full, empty roads, several cars past the road end so that handed-off cars cascade
     and envs take the serial advance, unsorted cars), every car with a random row of a four-row table whose exponents
-    are 1, 2, 4 and 8; bursts of arrivals of mixed rows; validate mode carries the spawn ticks beside the rows."""
+    are 1, 2, 4, 8, 2.5 and 0.75; bursts of arrivals of mixed rows; validate mode carries the spawn ticks beside the rows."""
     from test_gpu_parity import random_state
-    tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
-                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
-    tab10 = np.zeros((4, 10), np.float32)
+    tab8 = MIXED_ROWS
+    n_rows = len(tab8)
+    tab10 = np.zeros((n_rows, 10), np.float32)
     tab10[:, ROWS] = tab8
     m, n, L, E = 3, 2, 150.0, 4
     eng = TfxEngine(m, n, L, C, n_envs=E, planes=3, validate=validate, archetypes=tab8)
@@ -137,7 +137,7 @@ def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
     for trial in range(5):
         x, v, w, leading, lastcar = random_state(rng, E, eng.R, C, L, crowd=rng.choice([0.3, 0.8]),
                                                  beyond=rng.choice([0.0, 0.05, 0.4, 1.6]), sorted_x=bool(trial % 2))
-        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        arch = rng.randint(0, n_rows, size=x.shape).astype(np.uint8)
         phase = rng.randint(2, size=(E, eng.I)).astype(np.int32)
         eng.reset(phase)
         orc.reset(phase)
@@ -149,7 +149,7 @@ def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
         for t in range(8):
             act = rng.randint(2, size=(E, eng.I)).astype(np.int32)
             roads = [rng.choice(eng.entrypoints, size=rng.randint(0, 5)).tolist() for _ in range(E)]
-            rows = [rng.randint(0, 4, size=len(r)).tolist() for r in roads]
+            rows = [rng.randint(0, n_rows, size=len(r)).tolist() for r in roads]
             per_env = [spawn_rows(eng, r, a)[0] for r, a in zip(roads, rows)]
             S = max(p.shape[-1] for p in per_env)
             buf = np.zeros((E, max(1, eng.n_entry), S), np.uint8)
@@ -168,8 +168,10 @@ def test_mixed_rows_on_pathological_states_vs_oracle(C, validate):
                 assert np.array_equal(eng.trip_times[k, :nt[k]].cpu().numpy(), orc.trip_times[k, :nt[k]])
 
 
-FOUR_ROWS = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
-                      [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
+# exponents 4, 1, 2, 8 (multiply chains) and two that are no integers (include/tfx_pow.h)
+MIXED_ROWS = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
+                      [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3],
+                      [10.0, 5, 2.5, 2.5, 14.0, 5, 1.8, 1.5], [7.0, 6, 2.0, 0.75, 9.0, 4, 2.2, 2]], np.float32)
 
 
 @pytest.mark.parametrize("tail,split", [("2", "0"), ("0", "0"), ("2", "2")])
@@ -178,7 +180,7 @@ def test_mixed_rows_in_two_tick_pairs_vs_oracle(C, validate, tail, split):
     """The same pathological states through multi-tick calls: the HET forms of the two-tick pass, of k_edge / k_tail and
     the two-stream split (forced at test size).  A car's own row drives BOTH of its ticks in the pass, its leader's row
     the gap; arrivals of mixed rows come from per-tick count and row buffers."""
-    run_pairs_case(C, validate, tail, split, FOUR_ROWS, 60)
+    run_pairs_case(C, validate, tail, split, MIXED_ROWS, 60)
 
 
 @pytest.mark.parametrize("tail,split", [("2", "2"), ("0", "0")])
@@ -254,8 +256,7 @@ def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
     overflow."""
     from test_gpu_fused import engine_with
     from test_gpu_parity import random_state
-    tab8 = np.array([[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8.0, 8, 1.5, 1, 10.0, 4, 2.5, 2],
-                     [12.0, 3.5, 4, 2, 16.0, 7, 1.5, 1], [9.0, 12, 1.0, 8, 11.0, 3, 3.0, 3]], np.float32)
+    tab8 = MIXED_ROWS
     m, n, L, C, E = 3, 3, 120.0, 14, 9
     kw = dict(planes=3, m=m, n=n, length=L, capacity=C, archetypes=tab8)
     a = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": "2", "TFX_SPLIT": "2"}, E, **kw)
@@ -265,7 +266,7 @@ def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
     for trial, T in enumerate([3, 10, 4, 6]):
         x, v, w, leading, lastcar = random_state(rng, E, a.R, C, L, crowd=rng.choice([0.5, 0.9]),
                                                  beyond=rng.choice([0.0, 0.05, 0.4]), sorted_x=bool(trial % 2))
-        arch = rng.randint(0, 4, size=x.shape).astype(np.uint8)
+        arch = rng.randint(0, len(tab8), size=x.shape).astype(np.uint8)
         phase = rng.randint(2, size=(E, a.I)).astype(np.int32)
         act = rng.randint(2, size=(E, a.I)).astype(np.int32)
         period = int(rng.choice([1, 2, 5]))
@@ -299,8 +300,10 @@ def test_agent_steps_of_mixed_rows_on_a_handle_that_runs_pairs(remi):
 
 
 def test_unsupported_archetype_tables_are_refused():
-    with pytest.raises(TfxError):          # a non-integer exponent has no bit-exact power
-        TfxEngine(2, 2, 100.0, 10, planes=3, archetypes=[[11.11, 4, 3, 2.5, 13.89, 6, 2, 1]])
+    with pytest.raises(TfxError):          # an exponent outside (0, 64]
+        TfxEngine(2, 2, 100.0, 10, planes=3, archetypes=[[11.11, 4, 3, -1.0, 13.89, 6, 2, 1]])
+    frac = TfxEngine(2, 2, 100.0, 10, planes=3, archetypes=[[11.11, 4, 3, 2.5, 13.89, 6, 2, 1]])   # any other: per-car path
+    assert frac.het
     with pytest.raises(TfxError):          # several rows need the side word (planes = 3)
         TfxEngine(2, 2, 100.0, 10, planes=2, archetypes=[[11.11, 4, 3, 4, 13.89, 6, 2, 1], [8, 8, 1.5, 4, 10, 4, 2.5, 2]])
     eng = TfxEngine(2, 2, 100.0, 10, planes=2, archetypes=[[9.0, 5, 2, 4, 12.0, 5, 2, 1.5]])   # ONE ordinary row: fine

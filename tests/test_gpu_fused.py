@@ -55,7 +55,7 @@ def pertick_engine(E, **cfg):
 def test_fused_random_states_vs_oracle(m, n, C, length, sorted_x, layout):
     rng = np.random.RandomState(4321 + C + int(sorted_x))
     E, T = 5, 7
-    eng = fused_engine(E, epb=1 + C % 3, lpr=1 + int(sorted_x), layout=layout, planes=3 if layout == "ring" else 2,
+    eng = fused_engine(E, epb=1 + C % 3, lpr=(1, 2, 4)[(C // 2 + int(sorted_x)) % 3], layout=layout, planes=3 if layout == "ring" else 2,
                        m=m, n=n, length=length, capacity=C, rate=0.5)
     orc = oracle_like(eng)
     ran = 0

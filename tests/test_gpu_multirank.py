@@ -66,18 +66,26 @@ def test_two_ranks_on_one_gpu_equal_one_process(tmp_path):
     assert z["done"].shape == (7,)
 
 
-def test_bench_launches_two_ranks_rehearsal():
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_launches_its_ranks_rehearsal(ranks):
+    """`bench.py --gpus N` as the driver starts it, N ranks on GPU 0 over gloo: one JSON line, and in it what a scaling
+    curve needs beside the aggregate - the ranks' own times, the gather's duration, the spread over the timed regions."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["TFX_BENCH_REHEARSAL"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
-                        "--envs", "256"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       universal_newlines=True, timeout=400)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "20", "--warmup", "5",
+                        "--envs", "256", "--repeats", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == ranks and out["scaling"] == "weak" and out["value"] > 0
     assert "gather" in out["config"]["parallelism"] and out["config"]["envs_per_gpu"] == 256
+    assert out["repeats"] == 3 and out["spread"][0] <= out["value"] <= out["spread"][1]
+    assert out["per_rank_ms_per_step"]["min"] <= out["per_rank_ms_per_step"]["max"] == out["ms_per_step"]
+    assert out["t_max_over_t_min"] >= 1.0 and out["gather_ms_per_snapshot"] > 0
+    assert out["rccl_ranks_seen"] == 0          # (a rehearsal: gloo, no RCCL communicator)
+    assert out["agent_decision_ms"] > 0 and out["config"]["settle_ticks"] >= 0
 
 
 def test_snapshot_is_not_torn_by_the_ticks_that_follow():
@@ -172,11 +180,12 @@ def test_rccl_process_group_of_one_rank(tmp_path):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (this box has one)")
-def test_two_gpus_rccl_gather_equals_one_process(tmp_path):
-    """cfg3's code path for real: one rank per GPU, backend nccl (= RCCL over xGMI), uneven shards (151 + 150 envs,
-    so the padding of the smaller shard is exercised), four snapshots with ticks running behind each."""
+def test_rccl_gather_on_every_visible_gpu_equals_one_process(tmp_path):
+    """cfg3's code path for real: one rank per GPU - as many as the box shows, up to 8 - backend nccl (= RCCL over
+    xGMI), uneven shards (301 envs never divide evenly over 2..8 ranks, so the padding of the smaller shards is
+    exercised), four snapshots with ticks running behind each.  Runs the first time a multi-GPU box appears."""
     from gym_traffic import workload as wl
-    world = 2
+    world = min(8, torch.cuda.device_count())
     mp.spawn(_rccl_rank, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
     z = np.load(os.path.join(str(tmp_path), "gathered.npz"))
     ref = wl.setup_engine("cfg2", envs=301)

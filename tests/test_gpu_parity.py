@@ -37,7 +37,7 @@ def car_layout(request):
 # ... and through both step paths: the LDS-resident multi-tick kernel k_res (what small envs get by
 # default, packing 3 envs per workgroup so wavefronts straddle env boundaries) and the per-tick
 # streaming kernels (TFX_RESIDENT=0: what big envs get)
-@pytest.fixture(params=["resident", "resident1", "pertick", "pairs"], autouse=True)
+@pytest.fixture(params=["resident", "resident1", "resident4", "pertick", "pairs"], autouse=True)
 def step_path(request, monkeypatch):
     # "pairs": the per-tick kernels with two-tick passes (k_move_tt + k_edge) wherever a call has three ticks or more
     monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
@@ -46,7 +46,7 @@ def step_path(request, monkeypatch):
     if request.param.startswith("resident"):
         monkeypatch.setenv("TFX_RESIDENT", "1")
         monkeypatch.setenv("TFX_RES_EPB", "3")
-        monkeypatch.setenv("TFX_RES_LPR", "1" if request.param == "resident1" else "2")   # lanes per road
+        monkeypatch.setenv("TFX_RES_LPR", {"resident1": "1", "resident4": "4"}.get(request.param, "2"))   # lanes per road
     else:
         monkeypatch.setenv("TFX_RESIDENT", "0")
     yield request.param
@@ -212,7 +212,7 @@ def test_teacher_forced_vs_golden(name, golden_cache):
         live = live_mask(ld, lc, sc["C"])
         if live.any():
             assert_floats_match_reference(sx[live], sv[live], g["state_x"][at[k]][live], g["state_v"][at[k]][live],
-                                          rate=sc["rate"], where=(name, k))
+                                          rate=sc["rate"], where=(name, k), single_default_archetype=True)
             if eng.w is not None:
                 assert np.array_equal(sw[live], g["state_w"][at[k]][live])
 

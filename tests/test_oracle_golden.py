@@ -96,7 +96,8 @@ def test_teacher_forced_every_tick(name, golden_cache):
         if live.any():
             a_max = 3.0 if g.archetypes is None else float(g.archetypes[:, 3].max())
             assert_floats_match_reference(x[live], v[live], g["state_x"][at[k]][live], g["state_v"][at[k]][live],
-                                          a_max=a_max, rate=sc["rate"], where=(name, k))
+                                          a_max=a_max, rate=sc["rate"], where=(name, k),
+                                          single_default_archetype=g.archetypes is None)
             assert np.array_equal(w[live], g["state_w"][at[k]][live])
             if g.archetypes is not None:   # every car still carries the row it was spawned from, through every handoff
                 assert np.array_equal(env.arch_plane(0, g.archetypes)[live], g["state_a"][at[k]][live])

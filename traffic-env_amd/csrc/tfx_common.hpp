@@ -11,6 +11,7 @@
 #include <cstdint>
 
 #include "tfx.h"
+#include "tfx_pow.h"
 
 namespace tfx {
 
@@ -200,8 +201,12 @@ __device__ __forceinline__ void idm_step_het(const Dev &d, const float *me, floa
   const float s_star = me[AR_S0] + np_max0(t_gap + appr / me[AR_2SAB]);
   const float s = (xl - x) - ll;
   const float q = v / me[AR_V0];
-  const int delta = (int)me[AR_DELTA];
-  const float qd = delta == 4 ? pow4_cr(q) : powi_cr(q, delta);
+  // (v/v0)**delta: integer exponents 1..8 by their multiply chains (4: the single-archetype path's pow4_cr), anything
+  // else by the binary64 sequence the oracle shares (include/tfx_pow.h)
+  const float df = me[AR_DELTA];
+  const int delta = (int)df;
+  const float qd = (df == (float)delta && delta >= 1 && delta <= 8) ? (delta == 4 ? pow4_cr(q) : powi_cr(q, delta))
+                                                                    : tfx_pow_det(q, df);
   const float u = s_star / (s + d.eps);
   const float dv = me[AR_A] * ((1.0f - qd) - u * u);
   const float dvr = dv * d.rate;

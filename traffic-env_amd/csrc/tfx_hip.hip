@@ -107,8 +107,8 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
     const float single[8] = {cfg->car_v, cfg->car_l, cfg->car_a, cfg->car_delta, cfg->car_v0, cfg->car_b, cfg->car_T, cfg->car_s0};
     memcpy(arch_rows[a], cfg->n_archetypes >= 1 ? cfg->arch[a] : single, sizeof single);
     const float delta = arch_rows[a][3];
-    if (!(delta >= 1.0f && delta <= 8.0f) || delta != (float)(int)delta)
-      return fail(TFX_EINVAL, "archetype %d: delta = %g - only integers 1..8 have a bit-exact power (oracle powi_cr)", a, delta);
+    if (!(delta > 0.0f) || !(delta <= 64.0f))
+      return fail(TFX_EINVAL, "archetype %d: delta = %g - the exponent must be in (0, 64]", a, delta);
     if (delta != 4.0f) het = true;
     if (!(arch_rows[a][2] > 0.0f) || !(arch_rows[a][5] > 0.0f) || !(arch_rows[a][4] > 0.0f))
       return fail(TFX_EINVAL, "archetype %d: a, b and v0 must be > 0", a);

@@ -233,11 +233,16 @@ int res_configure(tfx_handle h) {
   h->res_epb = 0;
   if (const char *rv = getenv("TFX_RESIDENT")) if (atoi(rv) == 0) return TFX_OK;
   if (const char *mt = getenv("TFX_RES_MIN_TICKS")) h->res_min_ticks = atoi(mt);
-  int lpr_max = 2;
-  if (const char *lv = getenv("TFX_RES_LPR")) lpr_max = atoi(lv) == 1 ? 1 : 2;
+  // Lanes per road.  Two by default.  FOUR (8-car chains instead of 16 at cfg1) while the launch leaves the chip half
+  // empty - there a tick is as long as its longest chain: cfg1 x 256 envs, a 10-tick call 84 -> 64 us, a fused decision
+  // 74 -> 59; at 1024 envs the five wavefronts an env then takes no longer fit beside each other (16 per CU at this
+  // kernel's 128 registers) and the call takes 195 us instead of 106.  TFX_RES_LPR = 1 / 2 / 4 forces.
+  const long waves4 = ((long)4 * d.R + 63) / 64;
+  int lpr_max = ((long)d.E * waves4 <= (long)h->n_cu * 8) ? 4 : 2;
+  if (const char *lv = getenv("TFX_RES_LPR")) lpr_max = atoi(lv) == 1 ? 1 : (atoi(lv) == 4 ? 4 : 2);
   const char *ev = getenv("TFX_RES_EPB");
-  for (int lpr = lpr_max; lpr >= 1; --lpr) {
-    auto fits = [&](int epb) { return lpr == 2 ? res_try<2, W>(h, epb) : res_try<1, W>(h, epb); };
+  for (int lpr = lpr_max; lpr >= 1; lpr >>= 1) {
+    auto fits = [&](int epb) { return lpr == 4 ? res_try<4, W>(h, epb) : lpr == 2 ? res_try<2, W>(h, epb) : res_try<1, W>(h, epb); };
     if (!fits(1)) continue;  // (leaves the one-env configuration in place)
     if (ev) {
       int want = atoi(ev) < 1 ? 1 : atoi(ev);
@@ -249,7 +254,13 @@ int res_configure(tfx_handle h) {
     // 10-tick call 100 us against 172 with two envs, x 4096: 403 against 533 with three) - fewer
     // wavefronts meet at each barrier.  One lane per road: 80-lane envs leave wavefronts half empty, so
     // pack envs: the smallest number of equal rounds over the chip, E / (CUs * b) for b = 1, 2, ...
-    if (lpr == 2) return TFX_OK;
+    // (round 4, cfg1 x 4096 - three rounds of one-env workgroups over the chip: three envs per workgroup 360 us per
+    // 10-tick call against 417; at 1024 envs - one round - one env per workgroup stays ahead, 106 against 130)
+    if (lpr == 2) {
+      const long waves2 = ((long)2 * d.R + 63) / 64;
+      if ((long)d.E * waves2 >= (long)3 * h->n_cu * 16 && !fits(3)) (void)fits(1);
+    }
+    if (lpr >= 2) return TFX_OK;
     for (int b = 1; b <= 64; ++b) {
       const int epb = (d.E + h->n_cu * b - 1) / (h->n_cu * b);
       if (epb <= 1 || fits(epb)) break;
@@ -285,7 +296,10 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   a.own_clock = grid == 1 ? 1 : 0;
   h->step_kernel = "k_res";
   const dim3 g(grid), b(h->res_threads);
-  if (h->res_lpr == 2) {
+  if (h->res_lpr == 4) {
+    if (d.w) hipLaunchKernelGGL((k_res<4, true>), g, b, h->res_lds, st, d, a);
+    else hipLaunchKernelGGL((k_res<4, false>), g, b, h->res_lds, st, d, a);
+  } else if (h->res_lpr == 2) {
     if (d.w) hipLaunchKernelGGL((k_res<2, true>), g, b, h->res_lds, st, d, a);
     else hipLaunchKernelGGL((k_res<2, false>), g, b, h->res_lds, st, d, a);
   } else {

@@ -4,7 +4,7 @@
 // The per-tick kernels stream every car through HBM twice per tick and pay two launches per tick;
 // for small grids that is all latency (round 1: cfg1 x 1024 envs at 0.18 of the HBM roofline, 38 us
 // per tick of which the cars need 3).  Here a workgroup owns `epb` whole envs for the whole call:
-//   * LPR = 1 or 2 lanes per road (lanes = LPR * epb * R, packed across env boundaries so wavefronts
+//   * LPR = 1, 2 or 4 lanes per road (lanes = LPR * epb * R, packed across env boundaries so wavefronts
 //     stay full).  With two lanes the road's cars split in halves - the Jacobi update needs only OLD
 //     neighbours, so the second lane starts from the OLD state of the car in front of its half (read
 //     before the first lane, which sits next to it in the same wavefront, overwrites it) - and the
@@ -77,7 +77,7 @@ __host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, i
 template <int LPR, bool W>
 __global__ __launch_bounds__(RES_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_res(const Dev d, const ResArgs a) {
-  static_assert(LPR == 1 || LPR == 2, "one or two lanes per road");
+  static_assert(LPR == 1 || LPR == 2 || LPR == 4, "one, two or four lanes per road (adjacent lanes of one wavefront)");
   extern __shared__ __align__(16) unsigned char res_smem[];
   const int T = blockDim.x / LPR, C = d.C, NS = C - 1, R = d.R, I = d.I;  // T: road columns of the workgroup
   const int epb = a.epb;
@@ -98,9 +98,9 @@ void k_res(const Dev d, const ResArgs a) {
   int *s_gap = s_spawn + (size_t)epb * d.n_entry;  // [epb] whole ticks until the env's next car (-1: not drawn yet)
   unsigned *s_draws = reinterpret_cast<unsigned *>(s_gap + epb);  // [epb] index of the env's next car
 
-  const int h = LPR == 2 ? (int)(threadIdx.x & 1) : 0;  // which half of the road's cars this lane walks
+  const int h = (int)(threadIdx.x & (LPR - 1));  // which share (half, quarter) of the road's cars this lane walks
   const bool hA = h == 0;                                // the road's first lane also does everything per road
-  const int t = LPR == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x;  // the road's column
+  const int t = (int)(threadIdx.x / LPR);  // the road's column
   // Columns follow the storage-slot order of the env's roads (interior train roads, entry roads, exit
   // roads: build_slots) rather than road ids: roads of a kind have similar car counts, a wavefront
   // walks as far as its longest road, and a wavefront of short roads frees its SIMD early for the
@@ -334,23 +334,23 @@ void k_res(const Dev d, const ResArgs a) {
     }
     // ---- move_cars (:187-212): the lane walks its road from the head, leader chain in registers ---
     {
-      if (LPR == 2) {  // what the road's first lane worked out, for the second one
-        const int src = (int)(threadIdx.x & 62u);
+      if (LPR > 1) {  // what the road's first lane worked out, for the others
+        const int src = (int)(threadIdx.x & 63u & ~(unsigned)(LPR - 1));
         n_tot = __shfl(n_tot, src, 64);
         ld = __shfl(ld, src, 64);
         lc = __shfl(lc, src, 64);
         xL = __shfl(xL, src, 64);
       }
       // this lane's share of the road: cars [my_k0, my_k0 + my_n)
-      const int n_first = LPR == 2 ? (n_tot + 1) >> 1 : n_tot;
-      const int my_k0 = hA ? 0 : n_first;
-      const int my_n = run ? (hA ? n_first : n_tot - n_first) : 0;
+      const int n_share = (n_tot + LPR - 1) / LPR;
+      const int my_k0 = h * n_share;
+      const int my_n = run ? (n_tot - my_k0 < 0 ? 0 : (n_tot - my_k0 < n_share ? n_tot - my_k0 : n_share)) : 0;
       float xprev = xL, vprev = 0.0f, llv = 0.0f;
       const int head = wrap1(ld + 1, C);
-      if (LPR == 2 && !hA && my_n > 0) {
-        // the second half follows the last car of the first half: its OLD state, read here - before the
+      if (LPR > 1 && !hA && my_n > 0) {
+        // a later share follows the last car of the share before it: its OLD state, read here - before the
         // neighbouring lane (same wavefront, so in program order) rewrites that slot
-        const float2 lead = RG(ring_adv(head, n_first - 1, C), t);
+        const float2 lead = RG(ring_adv(head, my_k0 - 1, C), t);
         xprev = lead.x;
         vprev = lead.y;
         llv = d.car_l;
@@ -443,18 +443,24 @@ void k_res(const Dev d, const ResArgs a) {
           tail_x = act ? xn[u] : tail_x;
         }
       }
-      if (LPR == 2) {  // the halves meet in the road's first lane
-        const int kpop_b = __shfl_xor(kpop, 1, 64), wait_b = __shfl_xor(n_wait, 1, 64), det_b = __shfl_xor(n_det, 1, 64);
-        const int far_b = __shfl_xor((int)far, 1, 64), n_b = __shfl_xor(my_n, 1, 64);
-        const float tail_b = __shfl_xor(tail_x, 1, 64);
-        if (hA) {
-          if (open) {  // every car of the first half left: the pop prefix runs on into the second half
-            kpop += kpop_b;
-            far = far || (far_b != 0);
+      if (LPR > 1) {  // the shares meet in the road's first lane
+        const int base = (int)(threadIdx.x & 63u & ~(unsigned)(LPR - 1));
+        bool chain = open;  // every car so far left: the pop prefix runs on into the next share
+#pragma unroll
+        for (int j = 1; j < LPR; ++j) {
+          const int kpop_b = __shfl(kpop, base + j, 64), wait_b = __shfl(n_wait, base + j, 64), det_b = __shfl(n_det, base + j, 64);
+          const int far_b = __shfl((int)far, base + j, 64), n_b = __shfl(my_n, base + j, 64), open_b = __shfl((int)open, base + j, 64);
+          const float tail_b = __shfl(tail_x, base + j, 64);
+          if (hA) {
+            if (chain) {
+              kpop += kpop_b;
+              far = far || (far_b != 0);
+            }
+            chain = chain && (open_b != 0);
+            n_wait += wait_b;
+            n_det += det_b;
+            if (n_b > 0) tail_x = tail_b;
           }
-          n_wait += wait_b;
-          n_det += det_b;
-          if (n_b > 0) tail_x = tail_b;
         }
       }
       if (run && hA) {

@@ -102,7 +102,8 @@ def cpu_baseline(name, budget_s=12.0, max_ticks=20000):
     return {"value": updates / dt, "unit": "vehicle-updates/s", "cores": threads, "kind": "port",
             "one_core_value": one,
             "sample": "%d envs x %d ticks of %s (%.3g vehicle-updates in %.1f s), OpenMP over envs "
-                      "on %d threads, oracle/idm_oracle.c; then %d ticks on 1 thread (%.1f s)"
+                      "on %d threads, oracle/idm_oracle.c built gcc -O3 -ffp-contract=off -fopenmp (oracle/Makefile); "
+                      "then %d ticks on 1 thread (%.1f s)"
                       % (envs, ticks, name, updates, dt, threads, k, dt1)}
 
 

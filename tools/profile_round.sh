@@ -8,6 +8,9 @@ set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
+# the hash of every kernel's machine code in the library that runs below: travels with the counters (pmc_summary.py
+# stamps its summaries with it and refuses counters that come without)
+python3 $R/tools/kernel_hash.py > $O/kernel_hashes.json || { echo "kernel_hash failed"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
 prof() {  # name, rocprof args..., -- bench args
@@ -50,11 +53,12 @@ python3 bench.py --config cfg1 --envs 4096 --steps 1000 --warmup 600 --no-cpu-ba
 python3 bench.py --config cfg2 --envs 256 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_cfg2_256.json 2>/dev/null
 python3 bench.py --config cfg2 --envs 32768 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg2_32768.json 2>/dev/null
 ( python3 tools/bench_resident.py; python3 tools/bench_single_env.py ) 2>&1 | grep -v amdgpu.ids > $O/small_configs.txt
-( python3 tools/run_cfg4.py; python3 tools/c4_quick.py ) 2>&1 | grep -v amdgpu.ids > $O/cfg4_closed_loop.txt
+( python3 tools/run_cfg4.py; python3 tools/c4_loop.py 1; python3 tools/c4_loop.py 16 ) 2>&1 | grep -v amdgpu.ids > $O/cfg4_closed_loop.txt
 ( python3 tools/bench_agent_step.py cfg2; TFX_PAIRS=0 python3 tools/bench_agent_step.py cfg2 ) 2>&1 | grep -v amdgpu.ids > $O/agent_step_cfg2.txt
 # the driver's short run, with and without the workload's settle ticks; one rank with everything a rank of an N > 1 run does
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_cfg2_20steps.json 2>/dev/null
 python3 bench.py --steps 20 --warmup 5 --settle 0 --no-cpu-baseline > $O/bench_cfg2_20steps_nosettle.json 2>/dev/null
+python3 bench.py --steps 200 --warmup 20 --settle 0 --no-cpu-baseline > $O/bench_cfg2_nosettle.json 2>/dev/null
 python3 bench.py --rccl-one-rank --no-cpu-baseline > $O/bench_cfg2_rccl_one_rank.json 2>/dev/null
 ( python3 tools/bench_validate.py; TFX_PAIRS=0 python3 tools/bench_validate.py; python3 tools/bench_archetypes.py ) 2>&1 | grep -v amdgpu.ids > $O/validate_and_archetypes_cfg2.txt
 echo finished

@@ -60,7 +60,7 @@ struct Dev {
   uint8_t *hb;
   // per road, two-tick pass only (tfx_move_tt.hpp): what the pass hands to the edge work of the second tick, 12 bytes
   // (round 3: one 16-byte record): {v of the tail after the first tick, x of the tail after the second} and the
-  // waiting (both ticks so far) | detected << 16 (second tick so far) counts
+  // waiting (both ticks so far) | detected (second tick so far) | detected (first tick) counts (rec2c_pack)
   float2 *rec2f;
   int *rec2c;
   // A two-tick pass that k_tail follows (its CREC form) writes its road record in 8 bytes instead of rec's 16 - {pops |
@@ -379,6 +379,11 @@ __device__ __forceinline__ int rec_head(int rx) { return rx >> 16; }
 __device__ __forceinline__ int rec_ntot(int rw) { return rw & 0xffff; }
 __device__ __forceinline__ int rec_taila(int rw) { return rw >> 16; }
 
+// rec2c: waiting count of both ticks so far (10 bits) | detected of the second tick so far (9) << 10 | detected of the
+// first tick (9) << 19 | the road held cars in the first tick << 28
+__device__ __forceinline__ int rec2c_pack(int wait, int det1, int det0, bool had_cars) {
+  return wait | (det1 << 10) | (det0 << 19) | (had_cars ? 1 << 28 : 0);
+}
 __device__ __forceinline__ int crec_pack(int kpop, int n_tot, int taila, bool unc, bool ovf) {
   return kpop | (n_tot << 9) | (taila << 18) | (unc ? 1 << 24 : 0) | (ovf ? 1 << 25 : 0);
 }

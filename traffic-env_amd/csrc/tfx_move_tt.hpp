@@ -275,8 +275,8 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
     const int n_tot = p.n_tot;
     if (e < d.r) {
       int *ob = d.obs + (size_t)env * d.obs_len;
-      if (n_tot > 0) {
-        if (!two) d.waiting[(size_t)env * d.r + e] += n_wait;  // (a pair: k_edge adds both ticks' counts at once)
+      if (n_tot > 0 && !two) {  // (a pair: edge_tile adds both ticks' waiting counts at once and stores `detected` -
+        d.waiting[(size_t)env * d.r + e] += n_wait;  //  this tick's only if the road is empty in the next, :199-201)
         ob[d.r + e] = n_det;
       }
       // accumulates over the agent step (a pair: edge_tile adds both ticks' pops at once)
@@ -294,7 +294,7 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
     }
     if (two) {
       d.rec2f[id] = make_float2(y1v, tail_z);
-      d.rec2c[id] = (n_wait + n_wait1) | (n_det1 << 16);
+      d.rec2c[id] = rec2c_pack(n_wait + n_wait1, n_det1, n_det, n_tot > 0);
     }
     if (far || kpop > KP) d.env_flag[env] = tick + 1;
     if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
@@ -425,7 +425,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
   float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
 
-  int kpop = 0, n_wait = r2c & 0xffff, n_det = r2c >> 16;
+  int kpop = 0, n_wait = r2c & 1023, n_det = (r2c >> 10) & 511;
   bool open = true, far = false;
   const int kq = C - 1 - p.ld;
   float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
@@ -522,7 +522,10 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   if (e < d.r) {
     int *ob = d.obs + (size_t)env * d.obs_len;
     if (n_wait != 0) d.waiting[(size_t)env * d.r + e] += n_wait;
+    // `detected` keeps its last value while a road is empty (:199-201): this tick's count, or - the road emptied in this
+    // tick - the first tick's, which the pass handed over instead of storing it
     if (n_tot > 0) ob[d.r + e] = n_det;
+    else if ((r2c >> 28) & 1) ob[d.r + e] = (r2c >> 19) & 511;
     // (agent step: `passed` accumulates - this tick's pops and the pass's of the tick before; the first pair starts it)
     if (AGENT) ob[e] = (tidx > 1 ? ob[e] : 0) + rec_kpop(rc.x) + kpop;
     else if (full_out) ob[e] = kpop;

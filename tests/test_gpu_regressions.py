@@ -172,3 +172,33 @@ def test_fuzz_slice_vs_oracle():
     for seed in (20261004, 20261005):
         total += fz.run(seed, secs=8.0)
     assert total >= 4
+
+
+def test_fused_decisions_of_envs_too_big_for_k_tail():
+    """Round 4: sizing k_tail for an env whose ring words do not fit a workgroup's LDS (cfg4: 16 640 roads) asked HIP for
+    more dynamic LDS than exists; the refusal stayed behind as HIP's last error and the next launch of the captured
+    decision reported it (`hipGetLastError(): invalid argument` - bench.py --config cfg4 found it).  A grid of 6 560
+    roads (40 x 40) is past the limit as well: fused decisions in pairs, as a graph and eagerly, must run and equal the
+    tick-by-tick kernels."""
+    from test_gpu_fused import engine_with
+    kw = dict(m=40, n=40, length=120.0, capacity=10)
+    a = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2"}, 2, **kw)
+    b = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "0"}, 2, **kw)
+    c = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_GRAPH": "0"}, 2, **kw)
+    ph = np.zeros((2, a.I), np.int32)
+    for e in (a, b, c):
+        e.reset(ph)
+        e.set_spawns(period=2)
+        e.set_actions(cycle_period=7)
+    for _ in range(4):
+        ra = [t.clone() for t in a.agent_step(6, remi=True)]
+        rb = [t.clone() for t in b.agent_step(6, remi=True)]
+        rc = [t.clone() for t in c.agent_step(6, remi=True)]
+        for x, y, z in zip(ra, rb, rc):
+            assert torch.equal(x, y) and torch.equal(x, z)
+        a.step(5)
+        b.step(5)
+        c.step(5)
+    for name in ("leading", "lastcar", "obs", "rewards", "waiting"):
+        assert torch.equal(getattr(a, name), getattr(b, name)) and torch.equal(getattr(a, name), getattr(c, name)), name
+    assert a.pair_ticks() > 0 and a.tail_ticks() == 0 and int(a.cars_on_roads_flat().sum()) > 100

@@ -65,7 +65,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
       h->size_only = true;
       (void)launch_move_tt<true, true>(h, 0, nullptr);
       (void)launch_move_tt<false, true>(h, 0, nullptr);
-      (void)launch_tail(h, 0, nullptr, true);
+      if (tail_usable(h)) (void)launch_tail(h, 0, nullptr, true);
       h->size_only = false;
       (void)edge_grid(h);
     }

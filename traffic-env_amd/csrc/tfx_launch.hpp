@@ -493,13 +493,16 @@ bool split_usable(tfx_handle h, int n_ticks) {
   return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
 }
 
-// Workgroup size (the kernel takes any multiple of 64; TFX_TAIL_THREADS / TFX_TAIL_THREADS_HALF override for sweeps).
-// Round 3's unstaged k_tail: alone on the chip 256 lanes and as many workgroups as fit were best; as one half of a
-// split call, next to the other half's pass, 128 lanes (they fit the gaps the pass leaves).
+// Workgroup size (the kernel takes any multiple of 64).  Alone on the chip 256 lanes and as many workgroups as fit; as
+// one half of a split tfx_step call, next to the other half's pass, 128 lanes (they fit the gaps the pass leaves).
+// Round 4 sweep with the staged kernel, cfg2, ms per tick (64 / 128 / 192 / 256 lanes in the halves): 0.419 / 0.399 /
+// 0.406 / 0.414; workgroups per CU capped at 2 / 3 / as many as fit: 0.414 / 0.419 / 0.399.
 template <bool GREEDY, bool AGENT, bool W, bool HET>
 int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int flags) {
   auto kern = k_tail<GREEDY, AGENT, W, HET>;
   const size_t lds = tail_lds_bytes(h->d.R, h->d.I, HET);
+  // (asked of HIP it would fail - and leave its error behind for the next launch's hipGetLastError to find)
+  if (lds > TAIL_LDS_MAX) return fail(TFX_ESTATE, "an env's ring words (%zu bytes) do not fit a workgroup's LDS", lds);
   // The attribute belongs to the FUNCTION, not to the handle: only ever raised (see res_try)
   static size_t granted = 64 * 1024;
   if (lds > granted) {
@@ -508,12 +511,9 @@ int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int flags) {
   }
   if (h->grid_tail == 0) {
     for (int half = 0; half < 2; ++half) {
-      int threads = half ? 128 : 256;
-      if (const char *tv = getenv(half ? "TFX_TAIL_THREADS_HALF" : "TFX_TAIL_THREADS"))
-        if (atoi(tv) >= 64 && atoi(tv) <= 256 && atoi(tv) % 64 == 0) threads = atoi(tv);
+      const int threads = half ? 128 : 256;
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-      if (const char *pc = getenv("TFX_TAIL_BLOCKS_PER_CU")) per_cu = atoi(pc) > 0 ? atoi(pc) : per_cu;
       long g = (long)h->n_cu * per_cu;
       if (g > h->d.E) g = h->d.E;
       (half ? h->grid_tail_half : h->grid_tail) = (int)(g < 1 ? 1 : g);

@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--no-numpy-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions of --steps ticks each (fenced); the line reports their median and the spread")
+    ap.add_argument("--no-agent-steps", action="store_true",
+                    help="skip the measurement of fused agent decisions (profile runs: only the timed ticks' launches)")
     ap.add_argument("--settle", type=int, default=None,
                     help="untimed ticks run right after the prefill, as part of the workload's setup and before the W "
                          "warm-up steps (default: the workload's, gym_traffic/workload.py SETTLE_TICKS; 0 = none)")
@@ -440,20 +442,22 @@ def main():
     # a second handle brought to the state the first timed region started from (prefill, settle ticks, warm-up): late in a
     # long run the benchmark's entry roads run full, and an env that overflows in the first tick of a decision stands
     # still for the rest of it (`if done: break`) - which would time decisions that do nothing
-    eng2 = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
-    for n in [50] * (settle // 50) + [settle % 50, a.warmup]:
-        if n:
-            eng2.step(n)
-    n_dec = 5
-    eng2.agent_step(GATHER_EVERY, remi=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(n_dec):
-        adone = eng2.agent_step(GATHER_EVERY, remi=True)[2]
-    fence()
-    dt_agent = time.perf_counter() - t0
-    agent_done = int(adone.sum().item())
-    del eng2
+    n_dec, dt_agent, agent_done = 0, 0.0, 0
+    if not a.no_agent_steps:
+        eng2 = wl.setup_engine(a.config, device=device, envs=E, env_id_offset=rank * E)
+        for n in [50] * (settle // 50) + [settle % 50, a.warmup]:
+            if n:
+                eng2.step(n)
+        n_dec = 5
+        eng2.agent_step(GATHER_EVERY, remi=True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_dec):
+            adone = eng2.agent_step(GATHER_EVERY, remi=True)[2]
+        fence()
+        dt_agent = time.perf_counter() - t0
+        agent_done = int(adone.sum().item())
+        del eng2
 
     red_dev = torch.device("cpu") if rehearsal else device
     tt = torch.tensor([r[0] for r in regions] + [dt_agent], dtype=torch.float64, device=red_dev)
@@ -499,8 +503,8 @@ def main():
             "ms_per_step_spread": [min(times) / K * 1e3, max(times) / K * 1e3],
             "env_steps_per_sec": world * E * K / dt_max,
             # measured through tfx_agent_step (one decision = %d ticks + remi), not derived from the ticks above
-            "agent_steps_per_sec": world * E * n_dec / dt_agent_max,
-            "agent_decision_ms": dt_agent_max / n_dec * 1e3,
+            "agent_steps_per_sec": world * E * n_dec / dt_agent_max if n_dec else None,
+            "agent_decision_ms": dt_agent_max / n_dec * 1e3 if n_dec else None,
             "agent_decisions_timed": n_dec, "agent_envs_done_in_last_decision": agent_done,
             "regions": [{"ms": t * 1e3, "vehicle_updates": u} for t, u in zip(times, totals)],
             "mean_live_cars_per_road": updates / K / (E * eng.R),

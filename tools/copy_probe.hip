@@ -364,6 +364,9 @@ int main(int argc, char **argv) {
     TIME("in place, 16 B/lane, 4 rows", f4, 4, false, true, g);
     TIME("a -> b, 16 B/lane, 4 rows, nt", f4, 4, true, false, g);
     TIME("a -> b, 8 B/lane, 4 rows, nt", f2, 4, true, false, g);
+    // the per-road words of k_tail: 4 bytes per lane, default caching
+    TIME("in place, 4 B/lane, 4 rows", float, 4, false, true, g);
+    TIME("a -> b, 4 B/lane, 4 rows", float, 4, false, false, g);
   }
   // 48 of 64 rows live per road, as in the benchmark: every model line moves ~2.75 GB
   {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The FETCH_SIZE correction, measured on a stream of KNOWN size: tools/copy_probe.hip reads (and writes) 1 835 008 000
-# bytes per k_rw launch, 8 or 16 bytes per lane.  Prints FETCH_SIZE / WRITE_SIZE (KiB) per launch and their ratio to
+# bytes per k_rw launch, 4, 8 or 16 bytes per lane.  Prints FETCH_SIZE / WRITE_SIZE (KiB) per launch and their ratio to
 # the bytes really read / written.
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/fetch_factor; mkdir -p $O
@@ -18,9 +18,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(O + "/" + c + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_rw" in r["Kernel_Name"]:
-                agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+                agg[r["Kernel_Name"][:72]].append(float(r["Counter_Value"]))
     for k, v in sorted(agg.items()):
         m = sum(v) / len(v)
-        print("%-10s %-62s %3d launches  %12.0f KiB  = %.3f x the %.0f bytes each launch %s" %
+        print("%-10s %-74s %3d launches  %12.0f KiB  = %.3f x the %.0f bytes each launch %s" %
               (c, k, len(v), m, m * 1024 / BYTES, BYTES, "reads" if c == "FETCH_SIZE" else "writes"))
 PY

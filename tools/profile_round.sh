@@ -16,7 +16,7 @@ SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAV
 prof() {  # name, rocprof args..., -- bench args
   local name=$1; shift
   local rargs=(); while [ "$1" != "--" ]; do rargs+=("$1"); shift; done; shift
-  rocprofv3 "${rargs[@]}" -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" > $O/$name.log 2>&1 || echo "FAILED $name"
+  rocprofv3 "${rargs[@]}" -d $O/$name -o p --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --repeats 1 --no-agent-steps --no-cpu-baseline "$@" > $O/$name.log 2>&1 || echo "FAILED $name"
   echo "done $name"
 }
 # BENCH_ONLY=1: only the un-profiled bench lines below

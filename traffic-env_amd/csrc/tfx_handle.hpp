@@ -99,6 +99,11 @@ struct tfx_handle_s {
   hipGraphExec_t ag_exec = nullptr;
   hipStream_t ag_stream = nullptr;
   std::string ag_key;
+  // tfx_step calls of launch-bound handles replay a captured graph as well (step_graph, tfx_hip.hip)
+  hipGraph_t st_graph = nullptr;
+  hipGraphExec_t st_exec = nullptr;
+  std::string st_key;
+  long long st_pair = 0, st_tail = 0;  // what one replay adds to pair_ticks / tail_ticks
   // bumped by every call that changes something a captured kernel argument was built from (bound
   // buffers, action / spawn rules, the Poisson stream): part of the graph key, so a stale graph is
   // never replayed even when a re-allocated buffer lands on the address the old one had

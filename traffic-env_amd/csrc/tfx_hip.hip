@@ -17,6 +17,23 @@
 
 #include "tfx_sequence.hpp"
 
+namespace {
+
+// Everything a captured launch sequence bakes into its kernel arguments (a stale graph is never replayed, even when a
+// re-allocated buffer lands on the address the old one had: input_gen)
+void graph_key(tfx_handle h, char *key, size_t n, int n_ticks, int remi, const void *aobs, const void *areward,
+               const void *adone) {
+  const Dev &d = h->d;
+  snprintf(key, n, "%llu|%u|%u|%d.%d.%d.%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%ld|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
+           h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, h->ps.regular, h->ps.every, h->ps.burst, (int)h->poisson,
+           (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, aobs, areward, adone, (const void *)d.action,
+           d.action_mode, d.action_period, d.action_stride, (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv,
+           (void *)d.w, (void *)d.obs, (void *)d.rewards, (void *)d.leading, (void *)d.lastcar, (void *)d.waiting,
+           (void *)d.done_tick);
+}
+
+}  // namespace
+
 extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float *aobs, float *areward,
                               uint8_t *adone, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
@@ -25,7 +42,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
     return fail(TFX_EINVAL, "the fused agent step holds ONE action for all its ticks (bind the action buffer "
                             "with per_tick = 0)");
   hipStream_t st = (hipStream_t)stream;
-  const Dev &d = h->d;
+  (void)h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
   const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
   if (split) {
@@ -43,12 +60,7 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   }
   // one graph per distinct launch sequence: everything baked into kernel arguments is in the key
   char key[640];
-  snprintf(key, sizeof key, "%llu|%u|%u|%d.%d.%d.%d|%d%d%d|%ld|%d|%d|%p|%p|%p|%p|%d|%d|%p|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p",
-           h->input_gen, h->ps.seed_lo, h->ps.seed_hi, h->ps.n_cdf, h->ps.regular, h->ps.every, h->ps.burst, (int)h->poisson,
-           (int)h->greedy, h->greedy_spacing, d.spawn_stride, n_ticks, remi, (void *)aobs,
-           (void *)areward, (void *)adone, (const void *)d.action, d.action_mode, d.action_period,
-           (const void *)d.spawn, d.spawn_mode, d.spawn_period, (void *)d.xv, (void *)d.w, (void *)d.obs,
-           (void *)d.rewards, (void *)d.leading, (void *)d.lastcar, (void *)d.waiting, (void *)d.done_tick);
+  graph_key(h, key, sizeof key, n_ticks, remi, aobs, areward, adone);
   if (!h->ag_exec || h->ag_key != key) {
     if (h->ag_exec) { (void)hipGraphExecDestroy(h->ag_exec); h->ag_exec = nullptr; }
     if (h->ag_graph) { (void)hipGraphDestroy(h->ag_graph); h->ag_graph = nullptr; }
@@ -84,6 +96,76 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   h->pair_ticks += h->ag_pair;
   return TFX_OK;
 }
+
+namespace {
+
+// the launches of a tfx_step call on the per-tick kernels, on `st`
+int step_body(tfx_handle h, int n_ticks, hipStream_t st) {
+  if (int rc = launch_greedy(h, st)) return rc;  // (the decision of the call's first tick; later ones: advance_item)
+  if (h->poisson && n_ticks > 0) {
+    // the arrivals of the whole call (in chunks of the rows the count buffer holds) in ONE launch each: they depend
+    // on nothing but the stream, and a launch per tick was the longest one of a cfg4 tick
+    int rc = TFX_OK;
+    // a chunk's kernels count ticks from 0 (row t of the count buffer is the chunk's tick t); a per-tick ACTION buffer is
+    // indexed by the tick of the whole call, so its base moves along with the chunks
+    const int *const act0 = h->d.action;
+    for (int done = 0; done < n_ticks && rc == TFX_OK;) {
+      const int chunk = n_ticks - done < h->poisson_rows ? n_ticks - done : h->poisson_rows;
+      rc = launch_poisson(h, chunk, st);
+      h->d.spawn_stride = (long)h->d.E * h->d.n_entry;
+      if (act0 && h->action_per_tick) h->d.action = act0 + (size_t)done * h->d.action_stride;
+      if (rc == TFX_OK) rc = step_chunk(h, chunk, st);
+      h->d.spawn_stride = 0;
+      h->d.action = act0;
+      done += chunk;
+    }
+    return rc;
+  }
+  return step_chunk(h, n_ticks, st);
+}
+
+// the same as a captured graph: captured once per distinct sequence (graph_key), replayed afterwards
+int step_graph(tfx_handle h, int n_ticks, hipStream_t st) {
+  char key[640];
+  graph_key(h, key, sizeof key, n_ticks, -1, nullptr, nullptr, nullptr);
+  if (!h->st_exec || h->st_key != key) {
+    if (h->st_exec) { (void)hipGraphExecDestroy(h->st_exec); h->st_exec = nullptr; }
+    if (h->st_graph) { (void)hipGraphDestroy(h->st_graph); h->st_graph = nullptr; }
+    if (!h->ag_stream) HIPCHK(hipStreamCreateWithFlags(&h->ag_stream, hipStreamNonBlocking));
+    // grids are sized outside the capture (occupancy queries, function attributes)
+    h->size_only = true;
+    (void)launch_advance(h, 0, nullptr);
+    if (pairs_usable(h)) {
+      (void)launch_move_tt<true>(h, 0, nullptr);
+      (void)launch_move_tt<false>(h, 0, nullptr);
+      if (tail_usable(h)) (void)launch_tail(h, 0, nullptr);
+    } else {
+      (void)launch_move(h, 0, nullptr);
+    }
+    h->size_only = false;
+    if (pairs_usable(h)) (void)edge_grid(h);
+    const long long pair0 = h->pair_ticks, tail0 = h->tail_ticks;
+    HIPCHK(hipStreamBeginCapture(h->ag_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = step_body(h, n_ticks, h->ag_stream);
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(h->ag_stream, &g);
+    h->st_pair = h->pair_ticks - pair0;  // (the capture ran no kernel: every replay counts, see below)
+    h->st_tail = h->tail_ticks - tail0;
+    h->pair_ticks = pair0;
+    h->tail_ticks = tail0;
+    if (rc != TFX_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess) return fail(TFX_EDEVICE, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+    h->st_graph = g;
+    HIPCHK(hipGraphInstantiate(&h->st_exec, g, nullptr, nullptr, 0));
+    h->st_key = key;
+  }
+  HIPCHK(hipGraphLaunch(h->st_exec, st));
+  h->pair_ticks += h->st_pair;
+  h->tail_ticks += h->st_tail;
+  return TFX_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -309,6 +391,8 @@ int tfx_destroy(tfx_handle h) {
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->ag_exec) (void)hipGraphExecDestroy(h->ag_exec);
   if (h->ag_graph) (void)hipGraphDestroy(h->ag_graph);
+  if (h->st_exec) (void)hipGraphExecDestroy(h->st_exec);
+  if (h->st_graph) (void)hipGraphDestroy(h->st_graph);
   if (h->ag_stream) (void)hipStreamDestroy(h->ag_stream);
   if (h->split_stream) {
     (void)hipStreamSynchronize(h->split_stream);
@@ -552,27 +636,14 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
     }
     return TFX_OK;
   }
-  if (int rc = launch_greedy(h, st)) return rc;  // (the decision of the call's first tick; later ones: advance_item)
-  if (h->poisson && n_ticks > 0) {
-    // the arrivals of the whole call (in chunks of the rows the count buffer holds) in ONE launch each: they depend
-    // on nothing but the stream, and a launch per tick was the longest one of a cfg4 tick
-    int rc = TFX_OK;
-    // a chunk's kernels count ticks from 0 (row t of the count buffer is the chunk's tick t); a per-tick ACTION buffer is
-    // indexed by the tick of the whole call, so its base moves along with the chunks
-    const int *const act0 = h->d.action;
-    for (int done = 0; done < n_ticks && rc == TFX_OK;) {
-      const int chunk = n_ticks - done < h->poisson_rows ? n_ticks - done : h->poisson_rows;
-      rc = launch_poisson(h, chunk, st);
-      h->d.spawn_stride = (long)h->d.E * h->d.n_entry;
-      if (act0 && h->action_per_tick) h->d.action = act0 + (size_t)done * h->d.action_stride;
-      if (rc == TFX_OK) rc = step_chunk(h, chunk, st);
-      h->d.spawn_stride = 0;
-      h->d.action = act0;
-      done += chunk;
-    }
-    return rc;
-  }
-  return step_chunk(h, n_ticks, st);
+  // Launch-bound handles (a few thousand tiles: cfg4 x 16, a 16x16 grid x 256 envs) replay the call's launches as a HIP
+  // graph, like the fused agent step does: at cfg4 x 16 the kernels of a tick add up to 59 us of its 65.6
+  // (profiles/r04_cfg4_closed_loop_trace.txt).  Not while kernels are timed, not for calls that split over two streams.
+  const Dev &d = h->d;
+  if (h->use_graph && !h->prof && n_ticks >= 4 && d.layout == 1 && (long)d.E * d.G <= (long)h->n_cu * 24 &&
+      !split_usable(h, n_ticks))
+    return step_graph(h, n_ticks, st);
+  return step_body(h, n_ticks, st);
 }
 
 }  // extern "C"

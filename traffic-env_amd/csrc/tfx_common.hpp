@@ -63,9 +63,8 @@ struct Dev {
   // waiting (both ticks so far) | detected (second tick so far) | detected (first tick) counts (rec2c_pack)
   float2 *rec2f;
   int *rec2c;
-  // A two-tick pass that k_tail follows (its CREC form) writes its road record in 8 bytes instead of rec's 16 - {pops |
-  // cars on the road << 9 | table row of the tail << 18 | uncompacted << 24 | spawn overflows? << 25, bits of the tail's x}
-  // (crec_pack) - and the count of spawn overflows, when there are any, to ovf_cnt; k_tail expands it into its LDS copy
+  // A two-tick pass that k_tail follows (its CREC form) writes its road record in 8 bytes instead of rec's 16 - {packed
+  // integers (crec_pack), bits of the tail's x} - and the count of spawn overflows, when there are any, to ovf_cnt; k_tail expands it into its LDS copy
   // of rec, so the phase code reads what it always read
   int2 *crec;
   int *ovf_cnt;
@@ -384,13 +383,24 @@ __device__ __forceinline__ int rec_taila(int rw) { return rw >> 16; }
 __device__ __forceinline__ int rec2c_pack(int wait, int det1, int det0, bool had_cars) {
   return wait | (det1 << 10) | (det0 << 19) | (had_cars ? 1 << 28 : 0);
 }
-__device__ __forceinline__ int crec_pack(int kpop, int n_tot, int taila, bool unc, bool ovf) {
-  return kpop | (n_tot << 9) | (taila << 18) | (unc ? 1 << 24 : 0) | (ovf ? 1 << 25 : 0);
+// Two forms of crec.x.  Heterogeneous cars: pops | cars on the road << 9 | table row of the tail << 18 | uncompacted << 24
+// | spawn overflows? << 25.  Otherwise the cars on the road follow from the ring indices, and those ride along instead -
+// pops | leading << 9 | lastcar << 18 (ring slots: <= 257) | uncompacted << 27 | spawn overflows? << 28 - so that k_tail
+// need not load leading / lastcar (tfx_step calls; inside agent steps an env may have been skipped by the pass, and
+// k_tail loads them).
+template <bool HET>
+__device__ __forceinline__ int crec_pack(int kpop, int n_tot, int ld, int lc, int taila, bool unc, bool ovf) {
+  if (HET) return kpop | (n_tot << 9) | (taila << 18) | (unc ? 1 << 24 : 0) | (ovf ? 1 << 25 : 0);
+  return kpop | (ld << 9) | (lc << 18) | (unc ? 1 << 27 : 0) | (ovf ? 1 << 28 : 0);
 }
-// the 16-byte road record from its 8-byte form (ovf_sp: the spawn overflows, read from ovf_cnt when bit 25 is set; the
-// head slot of rec.x is a ring-layout notion and stays 0)
-__device__ __forceinline__ int4 crec_expand(int2 c, int ovf_sp) {
-  return make_int4(c.x & 511, rec_y(ovf_sp, (c.x >> 24) & 1), c.y, ((c.x >> 9) & 511) | (((c.x >> 18) & 63) << 16));
+template <bool HET>
+__device__ __forceinline__ bool crec_ovf(int cx) { return (cx >> (HET ? 25 : 28)) & 1; }
+// the 16-byte road record from its 8-byte form (ovf_sp: the spawn overflows, read from ovf_cnt when crec_ovf says so;
+// the head slot of rec.x is a ring-layout notion and stays 0)
+template <bool HET>
+__device__ __forceinline__ int4 crec_expand(int2 c, int ovf_sp, int C) {
+  if (HET) return make_int4(c.x & 511, rec_y(ovf_sp, (c.x >> 24) & 1), c.y, ((c.x >> 9) & 511) | (((c.x >> 18) & 63) << 16));
+  return make_int4(c.x & 511, rec_y(ovf_sp, (c.x >> 27) & 1), c.y, ring_count((c.x >> 9) & 511, (c.x >> 18) & 511, C));
 }
 
 // greedy.py:14-16: phase 1 iff the two N-S approaches hold more cars than the two E-W ones

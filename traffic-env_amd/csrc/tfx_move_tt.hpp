@@ -286,7 +286,7 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
     }
     if (TWO) tail_x = y1x;  // new x of the last car processed (0 if there was none)
     if (TWO && CREC) {  // (k_tail follows: 8 bytes instead of 16)
-      d.crec[id] = make_int2(crec_pack(kpop, n_tot, HET ? last_a : 0, kpop > KP, p.ovf_sp > 0), __float_as_int(tail_x));
+      d.crec[id] = make_int2(crec_pack<HET>(kpop, n_tot, p.ld, p.lc, HET ? last_a : 0, kpop > KP, p.ovf_sp > 0), __float_as_int(tail_x));
       if (p.ovf_sp > 0) d.ovf_cnt[id] = p.ovf_sp;
     } else {
       d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x),

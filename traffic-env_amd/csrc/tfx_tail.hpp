@@ -83,12 +83,18 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
       // needed 112 and the cfg2 tick went from 0.399 to 0.425 ms; within 80 registers no unrolling changed the tick.)
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
         const int2 c = d.crec[base + e];  // the pass's record in its 8-byte form
-        s_rec[e] = crec_expand(c, ((c.x >> 25) & 1) ? d.ovf_cnt[base + e] : 0);
-        s_ld[e] = d.leading[base + e];
-        s_lc[e] = d.lastcar[base + e];
-        s_tx[e] = d.tailx[base + e];
+        s_rec[e] = crec_expand<HET>(c, crec_ovf<HET>(c.x) ? d.ovf_cnt[base + e] : 0, d.C);
+        if (AGENT || HET) {  // (an env the pass skipped - frozen, sorted out - has no fresh record; HET: no room in it)
+          s_ld[e] = d.leading[base + e];
+          s_lc[e] = d.lastcar[base + e];
+          s_tx[e] = d.tailx[base + e];
+        } else {  // the ring indices ride in the record; the tail cache is rewritten by advance(t) before anyone reads it
+          s_ld[e] = (c.x >> 9) & 511;
+          s_lc[e] = (c.x >> 18) & 511;
+        }
+        // (the pass writes every column it walks compacted: only an env it skipped can have rows offset)
+        s_hb[e] = AGENT ? d.hb[base + e] : (uint8_t)0;
         if (HET) s_ta[e] = d.taila[base + e];
-        s_hb[e] = d.hb[base + e];
       }
       const int *lt = d.lights + (size_t)env * d.lights_stride;
       for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) s_lt[i] = lt[i];

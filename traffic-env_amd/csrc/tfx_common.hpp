@@ -58,6 +58,9 @@ struct Dev {
   // transposed layout: rows at the top of a road's column that hold no car (0..TFX_KP; see rec_hb) - a byte per road
   // of its own since round 4: the pass reads one byte instead of a 16-byte record, k_tail writes one back
   uint8_t *hb;
+  // k_tail<AGENT> only (LDS): 0 = the road's head cannot reach the road's end in the next tick - what edge_tile saw while
+  // it held the head's new state - so that the bound for the next pair (risk_lane) need not load the road's first rows
+  uint8_t *riskhint;
   // per road, two-tick pass only (tfx_move_tt.hpp): what the pass hands to the edge work of the second tick, 12 bytes
   // (round 3: one 16-byte record): {v of the tail after the first tick, x of the tail after the second} and the
   // waiting (both ticks so far) | detected (second tick so far) | detected (first tick) counts (rec2c_pack)

@@ -359,7 +359,8 @@ __device__ __forceinline__ bool risk_lane(const Dev &d, long tile, int env, int 
   // how many cars could leave: a prefix of the cars that can reach the end of the road at all
   const float2 *col = d.xv + ((size_t)tile * d.trows) * 64 + lane + (size_t)d.hb[id] * 64;
   int pops = 0;
-  for (int j = 0; j <= KP && j < n; ++j) {
+  const int n_look = (d.riskhint && d.riskhint[id] == 0) ? 0 : n;  // (0: edge_tile saw that the head cannot leave)
+  for (int j = 0; j <= KP && j < n_look; ++j) {
     const float2 c = col[(size_t)j * 64];
     const float reach = c.x + __builtin_fmaxf(d.rate * c.y + half_ar2, 0.0f);
     if (!(reach > d.length)) break;
@@ -430,6 +431,7 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   const int kq = C - 1 - p.ld;
   float lx = p.xL, lv = 0.0f, ll = 0.0f;  // OLD state of the car ahead of the next deferred car
   float tail_x = 0.0f;
+  float hx = 0.0f, hv = 0.0f;  // the new state of the road's head (the first deferred car)
   int last_a = HET ? rec_taila(rc.w) : 0;  // HET: table row of the road's last car so far
   // deferred car i (its tick-t state x, v) through tick t+1 against (lx, lv, ll); fresh: spawned this tick (side word sw)
   auto car = [&](int i, float x, float v, bool fresh, float sw = 0.0f) {
@@ -447,6 +449,10 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
     }
     lx = x;
     lv = v;
+    if (AGENT && i == 0) {
+      hx = zx;
+      hv = zv;
+    }
     const bool pop = open && (zx > d.length);
     open = pop;
     if (pop && kpop < KP) {
@@ -535,7 +541,14 @@ __device__ __forceinline__ int edge_tile(const Dev &d, long tile, int env, int l
   d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, unc),
                         __float_as_int(tail_x), n_tot | (HET ? last_a << 16 : 0));
   if (far || unc) d.env_flag[env] = tick + 1;
-  if (full_out) d.leadx[id] = p.xL;
+  if (full_out || AGENT) d.leadx[id] = p.xL;  // (k_tail<AGENT>: its LDS copy - stored when the decision or the env ends)
+  if (AGENT && d.riskhint) {
+    // can the head leave in the NEXT tick at all (risk_lane's first test, on the state this lane still holds)?  An empty
+    // road may receive a car in the advance, a head that left makes the next car the head: those roads load their rows
+    const float half_ar2 = (0.5f * (d.risk_a * d.rate)) * d.rate;
+    const bool check = n_tot == 0 || kpop > 0 || (hx + __builtin_fmaxf(d.rate * hv + half_ar2, 0.0f)) > d.length;
+    d.riskhint[id] = check ? 1 : 0;
+  }
   return n_tot;
 }
 

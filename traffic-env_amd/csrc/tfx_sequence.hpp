@@ -129,8 +129,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
         if (rc == TFX_OK) rc = launch_move_tt<true, true>(h, t, st, 0, tail);
         if (rc == TFX_OK && tail) {
           // the rest of the pair in one launch (the envs k_risk sorted out get their second tick inside it)
-          // (TAIL_LAST on every pair: an env that overflows stands still from there on, with what its last pair stored)
-          rc = launch_tail(h, t, st, true, (t + 3 < n_ticks ? TAIL_RISK_NEXT : 0) | TAIL_LAST);
+          rc = launch_tail(h, t, st, true, (t + 3 < n_ticks ? TAIL_RISK_NEXT : 0) | (t + 2 >= n_ticks ? TAIL_LAST : 0));
         } else {
           if (rc == TFX_OK) rc = launch_advance(h, t, st);
           if (rc == TFX_OK) rc = launch_inputs(h, st);

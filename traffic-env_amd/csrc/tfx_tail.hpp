@@ -36,7 +36,8 @@ enum { TAIL_RISK_NEXT = 1, TAIL_LAST = 2 };
 
 // bytes of LDS the staged form needs for one env
 inline size_t tail_lds_bytes(int R, int I, bool het) {
-  return (size_t)R * (sizeof(int4) + 3 * sizeof(int) + (het ? sizeof(int) : 0)) + (size_t)2 * I * sizeof(int) + (((size_t)R + 15) & ~(size_t)15);
+  // (+ k_tail<AGENT>: the fake leaders' x, 4 bytes, and the bound's hint, 1 byte, per road)
+  return (size_t)R * (sizeof(int4) + 4 * sizeof(int) + (het ? sizeof(int) : 0)) + (size_t)2 * I * sizeof(int) + 2 * (((size_t)R + 15) & ~(size_t)15);
 }
 
 // AGENT: inside an agent step (tfx_agent_step).  Envs that stand still are skipped by the phases themselves; envs k_risk
@@ -72,11 +73,19 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
   int *const s_ta = reinterpret_cast<int *>(s_tx + R);
   int *const s_lt = s_ta + (HET ? R : 0);
   uint8_t *const s_hb = reinterpret_cast<uint8_t *>(s_lt + 2 * d.I);
+  uint8_t *const s_hint = s_hb + ((R + 15) & ~15);                                  // AGENT
+  float *const s_lx = reinterpret_cast<float *>(s_hint + ((R + 15) & ~15));        // AGENT
 
   unsigned long long my_updates = 0;
   for (int env = blockIdx.x; env < d.E; env += gridDim.x) {
     Dev dl = d;
     const size_t base = (size_t)env * R;
+    // (workgroup-uniform) an env k_risk sorted out of this pair: its first tick could overflow; an env that stands still
+    const bool sorted_out = AGENT && risk_word(d, env, tidx) == tick + 1;
+    const bool frozen0 = AGENT && env_frozen(d, env, tick);
+    // The pass's record carries the ring indices (crec_pack) - unless the pass skipped the env, or the cars are
+    // heterogeneous (no room): then leading / lastcar, the tail cache and the row offsets are loaded.
+    const bool packed = !HET && !sorted_out && !frozen0;
     {
       // (Tried: the loads of 2 - 4 roads per lane in flight at once.  The kernel must stay within the registers of ONE
       // wavefront of the pass - 80 - to take the slots the other half's pass frees one for one: unrolled four times it
@@ -84,16 +93,16 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
         const int2 c = d.crec[base + e];  // the pass's record in its 8-byte form
         s_rec[e] = crec_expand<HET>(c, crec_ovf<HET>(c.x) ? d.ovf_cnt[base + e] : 0, d.C);
-        if (AGENT || HET) {  // (an env the pass skipped - frozen, sorted out - has no fresh record; HET: no room in it)
+        if (packed) {  // the tail cache is rewritten by advance(t) before anyone reads it; the pass left no row offsets
+          s_ld[e] = (c.x >> 9) & 511;
+          s_lc[e] = (c.x >> 18) & 511;
+          s_hb[e] = 0;
+        } else {
           s_ld[e] = d.leading[base + e];
           s_lc[e] = d.lastcar[base + e];
           s_tx[e] = d.tailx[base + e];
-        } else {  // the ring indices ride in the record; the tail cache is rewritten by advance(t) before anyone reads it
-          s_ld[e] = (c.x >> 9) & 511;
-          s_lc[e] = (c.x >> 18) & 511;
+          s_hb[e] = d.hb[base + e];
         }
-        // (the pass writes every column it walks compacted: only an env it skipped can have rows offset)
-        s_hb[e] = AGENT ? d.hb[base + e] : (uint8_t)0;
         if (HET) s_ta[e] = d.taila[base + e];
       }
       const int *lt = d.lights + (size_t)env * d.lights_stride;
@@ -105,12 +114,14 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
       dl.tailx = s_tx - base;
       if (HET) dl.taila = s_ta - base;
       dl.hb = s_hb - base;
+      if (AGENT) {
+        dl.leadx = s_lx - base;
+        dl.riskhint = sorted_out ? nullptr : s_hint - base;  // (a sorted-out env runs no edge work: no hints)
+      }
       dl.lights = s_lt;
       dl.lights_stride = 0;
       __syncthreads();
     }
-    // (workgroup-uniform) an env k_risk sorted out of this pair: its first tick could overflow
-    const bool sorted_out = AGENT && risk_word(d, env, tidx) == tick + 1;
     if (AGENT && sorted_out) {
       // The pass left this env's tiles alone.  Both of its ticks run here, one at a time - the one-tick pass over the
       // env's tiles by this workgroup's wavefronts, then its advance, twice.  An env that does overflow in tick t stands
@@ -156,6 +167,10 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
       }
       int *lt = d.lights + (size_t)env * d.lights_stride;
       for (int i = threadIdx.x; i < 2 * d.I; i += blockDim.x) lt[i] = s_lt[i];
+      // the fake leaders' x (tfx_export_ring reads them): when the decision ends, or the env does - it overflowed in
+      // this pair and stands still from here on with what its last tick left
+      if (AGENT && !frozen0 && (full_out || d.done_tick[env] > *d.agent_first))
+        for (int e = threadIdx.x; e < R; e += blockDim.x) d.leadx[base + e] = s_lx[e];
       __syncthreads();  // (the next env's loads overwrite the copies)
     }
   }

@@ -61,6 +61,11 @@ struct Dev {
   // k_tail<AGENT> only (LDS): 0 = the road's head cannot reach the road's end in the next tick - what edge_tile saw while
   // it held the head's new state - so that the bound for the next pair (risk_lane) need not load the road's first rows
   uint8_t *riskhint;
+  // "road state word": leading | lastcar << 9 | hb << 18 of a road, 4 bytes.  Between the pairs of ONE tfx_step call
+  // (plain cars, outside agent steps) k_tail writes this word instead of leading, lastcar and hb (9 bytes) and the next
+  // pass reads it instead of them (its RSW form); the call's last k_tail brings the reference's arrays up to date, its
+  // first pass reads those - nobody else looks at them in between.
+  int *rsw;
   // per road, two-tick pass only (tfx_move_tt.hpp): what the pass hands to the edge work of the second tick, 12 bytes
   // (round 3: one 16-byte record): {v of the tail after the first tick, x of the tail after the second} and the
   // waiting (both ticks so far) | detected (second tick so far) | detected (first tick) counts (rec2c_pack)
@@ -317,14 +322,28 @@ __device__ __forceinline__ int spawn_count(const Dev &d, int env, int e, int ej,
 struct RoadPrep {
   int ld, lc, n_old, n_tot, ovf_sp;
   float xL, xs0;  // fake-leader x; x of the first car spawned this tick
+  int hb;         // RSW form: rows that hold no car at the top of the road's column (otherwise the caller reads d.hb)
 };
 
+__device__ __forceinline__ int rsw_pack(int ld, int lc, int hb) { return ld | (lc << 9) | (hb << 18); }
+
+// RSW: the ring indices come from the road state words (Dev::rsw) and a spawn's new lastcar is not stored (k_tail, which
+// follows, takes it from the pass's record)
+template <bool RSW = false>
 __device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int e, int tick,
                                               int tick_mod_period, int tidx, bool valid, bool store) {
   const int C = d.C;
   RoadPrep p;
-  p.ld = d.leading[id];
-  p.lc = d.lastcar[id];
+  if (RSW) {
+    const int w = d.rsw[id];
+    p.ld = w & 511;
+    p.lc = (w >> 9) & 511;
+    p.hb = (w >> 18) & 3;
+  } else {
+    p.ld = d.leading[id];
+    p.lc = d.lastcar[id];
+    p.hb = 0;
+  }
   p.n_old = ring_count(p.ld, p.lc, C);
   p.n_tot = p.n_old;
   p.ovf_sp = 0;
@@ -339,7 +358,14 @@ __device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int
       p.xL = d.length;
     } else {
       const int idn = env * d.R + d.nexts[e];
-      if (d.lastcar[idn] != d.leading[idn]) p.xL = d.tailx[idn] + d.length;
+      bool occupied;
+      if (RSW) {
+        const int wn = d.rsw[idn];
+        occupied = ((wn >> 9) & 511) != (wn & 511);
+      } else {
+        occupied = d.lastcar[idn] != d.leading[idn];
+      }
+      if (occupied) p.xL = d.tailx[idn] + d.length;
     }
   }
   const int ej = d.entry_idx[e];
@@ -360,7 +386,7 @@ __device__ __forceinline__ RoadPrep prep_road(const Dev &d, int id, int env, int
           ++p.ovf_sp;
         }
       }
-      if (store && p.n_tot != p.n_old) d.lastcar[id] = p.lc;
+      if (!RSW && store && p.n_tot != p.n_old) d.lastcar[id] = p.lc;
     }
   }
   return p;

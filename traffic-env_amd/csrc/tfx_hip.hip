@@ -288,6 +288,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   const size_t o_rec2c = off; off = align_up(off + (d.layout == 1 ? ER * sizeof(int) : 0), 256);
   const size_t o_crec = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int2) : 0), 256);
   const size_t o_ovfc = off;  off = align_up(off + (d.layout == 1 ? ER * sizeof(int) : 0), 256);
+  const size_t o_rsw = off;   off = align_up(off + (d.layout == 1 ? ER * sizeof(int) : 0), 256);
   const size_t o_tail = off;  off = align_up(off + ER * sizeof(float), 256);
   const size_t o_flag = off;  off = align_up(off + (size_t)d.E * sizeof(int), 256);
   const size_t o_risk = off;  off = align_up(off + 2 * (size_t)d.E * sizeof(int), 256);
@@ -319,6 +320,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   d.rec2c = (int *)(base + o_rec2c);
   d.crec = d.layout == 1 ? (int2 *)(base + o_crec) : nullptr;
   d.ovf_cnt = d.layout == 1 ? (int *)(base + o_ovfc) : nullptr;
+  d.rsw = d.layout == 1 ? (int *)(base + o_rsw) : nullptr;
   d.tailx = (float *)(base + o_tail);
   d.env_flag = (int *)(base + o_flag);
   d.env_risk = (int *)(base + o_risk);

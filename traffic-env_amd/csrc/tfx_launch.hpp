@@ -377,8 +377,9 @@ int edge_grid(tfx_handle h) {
 
 // AGENT: inside an agent step; only_risky: the second tick of the envs k_risk sorted out of a pair
 // crec: k_tail follows this (two-tick) pass - the road records go out in their 8-byte form (Dev::crec)
+// rsw: ... and a k_tail of the same call came before it - the ring indices come from its road state words (Dev::rsw)
 template <bool TWO, bool AGENT = false>
-int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, bool crec = false) {
+int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, bool crec = false, bool rsw = false) {
   // Grid: 10 workgroups per CU, 6 of them resident at once.  Measured at cfg2 (ms per pass alone on the chip
   // / vehicle-updates per second of the split call, same box): 6 workgroups per CU - every one resident for the whole
   // launch - 0.741 / 5.22-5.26e11; 10-12 per CU 0.706-0.719 / 5.26e11; 24 per CU 0.682 / 5.15e11; one tile per
@@ -408,7 +409,11 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   const bool stagger = TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
   const dim3 g((unsigned)grid), b(256);
-  if (TWO && crec) {  // (k_tail follows)
+  if (TWO && crec && rsw && !AGENT && !h->d.het) {
+    constexpr bool CR = TWO && !AGENT;
+    if (h->d.w) hipLaunchKernelGGL((k_move_tt<CR, false, true, false, CR, CR>), g, b, 0, st, h->d, tidx, only_risky);
+    else hipLaunchKernelGGL((k_move_tt<CR, false, false, false, CR, CR>), g, b, 0, st, h->d, tidx, only_risky);
+  } else if (TWO && crec) {  // (k_tail follows)
     constexpr bool CR = TWO;
     if (h->d.het) hipLaunchKernelGGL((k_move_tt<CR, AGENT, true, true, CR>), g, b, 0, st, h->d, tidx, only_risky);
     else if (h->d.w) hipLaunchKernelGGL((k_move_tt<CR, AGENT, true, false, CR>), g, b, 0, st, h->d, tidx, only_risky);
@@ -445,6 +450,7 @@ Dev sub_dev(const tfx_handle_s *h, int lo, int n, int *clock) {
   if (d.n_trips) s.n_trips = d.n_trips + L;
   s.rec = d.rec + L * R;
   s.rec2f = d.rec2f + L * R;
+  if (d.rsw) s.rsw = d.rsw + L * R;
   if (d.crec) {
     s.crec = d.crec + L * R;
     s.ovf_cnt = d.ovf_cnt + L * R;

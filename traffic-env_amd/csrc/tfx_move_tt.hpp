@@ -71,7 +71,9 @@ namespace tfx {
 // heads and joiners through tick + 1 as well.  Returns the lane's vehicle-updates of tick `tick`.  Reads and writes the
 // ring words (leading, lastcar, tailx, rec, the light words) through `d`.
 // CREC: k_tail follows this (two-tick) pass - the road record goes out in its 8-byte form (Dev::crec)
-template <bool TWO, bool AGENT, bool W, bool HET, bool CREC = false>
+// RSW (with CREC, plain cars, outside agent steps): not the first pair of its call - the ring indices and the row offset
+// come from the road state words the k_tail before it left (Dev::rsw)
+template <bool TWO, bool AGENT, bool W, bool HET, bool CREC = false, bool RSW = false>
 __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const int env, const int lane, const int tick,
                                             const int tick_sp, const int tidx, const bool two, const float *s_arch,
                                             const bool skip = false) {
@@ -83,11 +85,11 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
   const int id = env * d.R + e;
   // (no early exit for a tile that is skipped or stands still: the words that say so are loaded side by side with the
   // rest of the prologue instead of ahead of it - an early `continue` cost the agent pass 9 % of its time)
-  const int hb0 = valid ? d.hb[id] : 0;  // rows the second tick of the last pair left empty at the top of the column
+  const int hb0 = (valid && !RSW) ? d.hb[id] : 0;  // rows the second tick of the last pair left empty at the top of the column
   const bool run = valid && !skip && !(AGENT && env_frozen(d, env, tick));
-  const int hb = run ? hb0 : 0;
-  if (hb) d.hb[id] = 0;               // (this walk writes the column compacted; nobody else reads the byte meanwhile)
-  const RoadPrep p = prep_road(d, id, env, e, tick, tick_sp, tidx, run, run);
+  const RoadPrep p = prep_road<RSW>(d, id, env, e, tick, tick_sp, tidx, run, run);
+  const int hb = run ? (RSW ? p.hb : hb0) : 0;
+  if (!RSW && hb) d.hb[id] = 0;       // (this walk writes the column compacted; nobody else reads the byte meanwhile)
   const int n_old = run ? p.n_old : 0;
   const int n_sp = run ? p.n_tot - p.n_old : 0;
 
@@ -303,9 +305,10 @@ __device__ __forceinline__ int move_tt_tile(const Dev &d, const long tile, const
   return 0;
 }
 
-template <bool TWO, bool AGENT = false, bool W = false, bool HET = false, bool CREC = false>
+template <bool TWO, bool AGENT = false, bool W = false, bool HET = false, bool CREC = false, bool RSW = false>
 __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const int tidx, const int only_risky) {
   static_assert(!CREC || TWO, "only a two-tick pass is followed by k_tail");
+  static_assert(!RSW || (CREC && !AGENT && !HET), "road state words: between the pairs of a plain tfx_step call");
   static_assert(!HET || W, "heterogeneous cars carry their table row in the side word");
   __shared__ float s_arch[HET ? TFX_MAX_ARCH * ARCH_W : 1];
   if (HET) load_arch(d, s_arch);
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_move_tt(const Dev d, const i
     // (a stamp left by an earlier run at the same tick number - the clock can be set back - is honoured all the
     // way: this pass takes the tile one tick at a time, k_edge skips it, and the restricted launch must come)
     if (AGENT && TWO && !two && lane == 0) risk_any_word(d, tidx) = tick + 1;
-    my_updates += (unsigned long long)move_tt_tile<TWO, AGENT, W, HET, CREC>(d, tile, env, lane, tick, tick_sp, tidx, two, s_arch,
+    my_updates += (unsigned long long)move_tt_tile<TWO, AGENT, W, HET, CREC, RSW>(d, tile, env, lane, tick, tick_sp, tidx, two, s_arch,
                                                                             CREC && sorted_out);
   }
 

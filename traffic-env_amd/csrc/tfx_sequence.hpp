@@ -177,10 +177,12 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
       hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
       if (int rc = launch_inputs(h, st)) return rc;
       if (timed) HIPCHK(hipEventRecord(e[0], st));
-      if (int rc = launch_move_tt<true>(h, t, st, 0, tail_usable(h))) return rc;
+      // (from a call's second pair on the pass reads the road state words the k_tail before it left; the last k_tail
+      // of the call stores leading / lastcar / hb themselves)
+      if (int rc = launch_move_tt<true>(h, t, st, 0, tail_usable(h), t > 0)) return rc;
       if (timed) HIPCHK(hipEventRecord(e[1], st));
       if (tail_usable(h)) {
-        if (int rc = launch_tail(h, t, st, false, t + 2 >= n_ticks ? TAIL_LAST : 0)) return rc;
+        if (int rc = launch_tail(h, t, st, false, (t + 2 >= n_ticks ? TAIL_LAST : 0) | (t + 3 >= n_ticks ? TAIL_SYNC : 0))) return rc;
         h->tail_ticks += 2;
       } else {
         if (int rc = launch_advance(h, t, st)) return rc;

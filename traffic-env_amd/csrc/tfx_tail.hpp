@@ -32,7 +32,7 @@
 namespace tfx {
 
 // k_tail's flags
-enum { TAIL_RISK_NEXT = 1, TAIL_LAST = 2 };
+enum { TAIL_RISK_NEXT = 1, TAIL_LAST = 2, TAIL_SYNC = 4 };
 
 // bytes of LDS the staged form needs for one env
 inline size_t tail_lds_bytes(int R, int I, bool het) {
@@ -46,6 +46,8 @@ inline size_t tail_lds_bytes(int R, int I, bool het) {
 // the same decision - the last phase evaluates k_risk's bound for it (the state it needs is what advance(t + 1) has
 // just left in LDS), so only the first pair of a decision pays a k_risk launch.
 // flags & TAIL_LAST: the last pair of its call - the outputs only a caller can read are stored (edge_tile's full_out).
+// flags & TAIL_SYNC: no pair follows in this call - leading, lastcar and hb are stored; otherwise (plain cars, outside
+// agent steps) only the road state words the next pass reads (Dev::rsw: 4 bytes per road instead of 9).
 // W: validate mode - the cars' side words travel along (edge_tile)
 // HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
 // from an LDS copy of the table
@@ -159,9 +161,14 @@ __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int 
     {
       __syncthreads();
       for (int e = threadIdx.x; e < R; e += blockDim.x) {
-        d.hb[base + e] = s_hb[e];  // (the road records themselves are dead: the next pass writes new ones)
-        d.leading[base + e] = s_ld[e];
-        d.lastcar[base + e] = s_lc[e];
+        // (the road records themselves are dead: the next pass writes new ones)
+        if (AGENT || HET || (flags & TAIL_SYNC)) {
+          d.hb[base + e] = s_hb[e];
+          d.leading[base + e] = s_ld[e];
+          d.lastcar[base + e] = s_lc[e];
+        } else {
+          d.rsw[base + e] = rsw_pack(s_ld[e], s_lc[e], s_hb[e]);
+        }
         d.tailx[base + e] = s_tx[e];
         if (HET) d.taila[base + e] = s_ta[e];
       }

@@ -371,3 +371,60 @@ def test_cfg1_full_batch_default_resident_packing_vs_oracle(monkeypatch):
             assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (dec, k)
             assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (dec, k)
     assert eng.step_kernel() == "k_res"
+
+
+@pytest.mark.parametrize("envs,expect", [(600, "split"), (300, "tail"), (96, "pairs"), (40, "graph")])
+def test_default_heuristics_at_mid_batches_vs_oracle(envs, expect, monkeypatch):
+    """The handle's OWN choices (no TFX_* switch set) between the headline batch and the tiny ones the rest of the suite
+    forces paths on: 600 envs of the 16x16 grid take pairs + k_tail in two halves on two streams, 300 pairs + k_tail in
+    one range, 96 pairs with the three per-road launches, 40 the tick-by-tick kernels - the launch-bound ones replayed
+    as a HIP graph.  Calls of even and odd lengths and fused decisions in between; sampled envs equal the oracle bit for
+    bit, and the counters say the expected path ran."""
+    for var in ("TFX_RES_EPB", "TFX_RES_LPR", "TFX_RESIDENT", "TFX_RES_MIN_TICKS", "TFX_PAIRS", "TFX_LAYOUT", "TFX_TAIL",
+                "TFX_SPLIT", "TFX_MOVE_VARIANT", "TFX_GRAPH", "TFX_KINDS", "TFX_FASTDIV"):
+        monkeypatch.delenv(var, raising=False)
+    c = wl.CONFIGS["cfg2"]
+    eng = wl.setup_engine("cfg2", envs=envs)
+    C = eng.C
+    sample = [0, envs // 2 - 1, envs // 2, envs - 1]
+    orcs = [oracle_for(eng, c, 1, k) for k in sample]
+    t = 0
+    for chunk in [2, 7, 10, 1, 6, 5]:
+        eng.step(chunk)
+        for _ in range(chunk):
+            for (orc, ids) in orcs:
+                step_oracle(orc, ids, eng, t, threads=1)
+            t += 1
+        ld, lc = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
+        for (orc, ids), k in zip(orcs, sample):
+            assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (t, k)
+            assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]), (t, k)
+            assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (t, k)
+            assert np.array_equal(eng.rewards[k].cpu().numpy(), orc.rewards[0]), (t, k)
+    for (orc, ids), k in zip(orcs, sample):
+        live = live_mask(ld[k], lc[k], C)
+        xk, vk = eng.x[k].cpu().numpy(), eng.v[k].cpu().numpy()
+        assert np.array_equal(xk[live].view(np.int32), orc.x[0][live].view(np.int32)), k
+        assert np.array_equal(vk[live].view(np.int32), orc.v[0][live].view(np.int32)), k
+    pairs = 2 + 6 + 10 + 6 + 4
+    if expect == "split":
+        assert eng.pair_ticks() == pairs and eng.tail_ticks() == pairs and eng.split_ticks() == 2 + 7 + 10 + 6 + 5
+    elif expect == "tail":
+        assert eng.pair_ticks() == pairs and eng.tail_ticks() == pairs and eng.split_ticks() == 0
+    elif expect == "pairs":
+        assert eng.pair_ticks() == pairs and eng.tail_ticks() == 0 and eng.split_ticks() == 0
+    else:
+        assert eng.pair_ticks() == 0 and eng.step_kernel() in ("k_move_t", "k_move_ts")
+    # a fused decision on the same handle, against a second handle that takes it tick by tick
+    ref = wl.setup_engine("cfg2", envs=envs)
+    ref.step(31)
+    monkeypatch.setenv("TFX_PAIRS", "0")
+    slow = wl.setup_engine("cfg2", envs=envs)
+    monkeypatch.delenv("TFX_PAIRS")
+    slow.step(31)
+    for _ in range(2):
+        ra = [x.clone() for x in ref.agent_step(10, remi=True)]
+        rb = [x.clone() for x in slow.agent_step(10, remi=True)]
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    assert torch.equal(ref.leading, slow.leading) and torch.equal(ref.obs, slow.obs) and torch.equal(ref.waiting, slow.waiting)

@@ -114,3 +114,31 @@ print("ok")
                UBSAN_OPTIONS="halt_on_error=1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_shared_power_function_is_the_rounded_binary64_power():
+    """include/tfx_pow.h (the (v/v0)**delta of exponents that are no integers in 1..8, compiled by the oracle AND by the HIP
+    kernels): against RN32(pow64(q, delta)) - the correctly rounded result but for values within ~1e-8 ulp of a boundary -
+    over a sample of bases and exponents, plus the special values.  (HIP == oracle bit for bit on this function is what
+    the fractional-delta archetype tests of the GPU suite check.)"""
+    import ctypes
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "p.c")
+        open(src, "w").write('#include "tfx_pow.h"\nfloat f(float q, float d) { return tfx_pow_det(q, d); }\n')
+        so = os.path.join(tmp, "p.so")
+        subprocess.check_call(["gcc", "-O3", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), "-o", so, src])
+        lib = ctypes.CDLL(so)
+        lib.f.restype = ctypes.c_float
+        lib.f.argtypes = [ctypes.c_float, ctypes.c_float]
+        rng = np.random.RandomState(3)
+        qs = np.concatenate([rng.uniform(0, 2, 15000), np.exp(rng.uniform(-30, 5, 15000))]).astype(np.float32)
+        ds = rng.choice([0.5, 0.75, 1.5, 2.5, 3.7, 4.5, 7.3, 0.01, 12.0, 33.3, 64.0], size=qs.size).astype(np.float32)
+        with np.errstate(over="ignore"):
+            want = (qs.astype(np.float64) ** ds.astype(np.float64)).astype(np.float32)
+        got = np.array([lib.f(float(q), float(d)) for q, d in zip(qs, ds)], np.float32)
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        assert lib.f(0.0, 2.5) == 0.0 and lib.f(1.0, 2.5) == 1.0 and lib.f(float("inf"), 0.3) == float("inf")
+        assert np.isnan(lib.f(float("nan"), 2.5)) and lib.f(1e-40, 2.5) == 0.0 and lib.f(3e38, 2.5) == float("inf")

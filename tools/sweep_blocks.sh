@@ -1,7 +1,6 @@
-#!/bin/bash
-# bench.py (cfg2) for several values of TFX_MOVE_BLOCKS_PER_CU: tools/sweep_blocks.sh 6 8 10 12
-cd ${GRAFT_REPO_ROOT:-.}
-for b in "$@"; do
-  TFX_MOVE_BLOCKS_PER_CU=$b python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('blocks/CU %s: %.4g  %.4f ms/tick  pass %.4f ms' % ('$b', d['value'], d['ms_per_step'], d['roofline']['launch_ms']))"
+# Sweep of the two-tick pass's grid (workgroups per CU) for the split call: ms/tick, veh-upd/s, pass launch ms, agent decision ms
+cd $GRAFT_REPO_ROOT
+for b in ${BLOCKS:-0 15 16 17 0 16 17}; do
+  if [ $b = 0 ]; then unset TFX_MOVE_BLOCKS_PER_CU; else export TFX_MOVE_BLOCKS_PER_CU=$b; fi
+  python3 bench.py --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('blocks/CU $b', round(d['ms_per_step'],4), '%.4g'%d['value'], round(d['roofline']['launch_ms'],4), 'agent', round(d['agent_decision_ms'],3))"
 done

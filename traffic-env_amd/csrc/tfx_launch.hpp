@@ -380,13 +380,15 @@ int edge_grid(tfx_handle h) {
 // rsw: ... and a k_tail of the same call came before it - the ring indices come from its road state words (Dev::rsw)
 template <bool TWO, bool AGENT = false>
 int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, bool crec = false, bool rsw = false) {
-  // Grid: 10 workgroups per CU, 6 of them resident at once.  Measured at cfg2 (ms per pass alone on the chip
-  // / vehicle-updates per second of the split call, same box): 6 workgroups per CU - every one resident for the whole
-  // launch - 0.741 / 5.22-5.26e11; 10-12 per CU 0.706-0.719 / 5.26e11; 24 per CU 0.682 / 5.15e11; one tile per
-  // wavefront (68 per CU) 0.681 / 5.12e11; another box 6 / 10 / 12 per CU: 0.749 / 0.716 / 0.722 and 5.13 / 5.14 /
-  // 5.08e11.  A second, partial round of workgroups evens out the end of the launch; more rounds
-  // cost the split call more than they give the launch.  (Grids of a whole number of workgroups per CU: an "exactly
-  // balanced" 2902 instead of 3072 workgroups took 0.756.)
+  // Grid: 16 workgroups per CU, 6 of them resident at once: later rounds of workgroups even out the end of the launch.
+  // Measured at cfg2, round 4 (k_tail with its lighter records), split call, same box, workgroups per CU -> ms per tick /
+  // ms per pass on the chip: 6 -> 0.396 / 0.739; 8 -> 0.404 / 0.755; 10 -> 0.387-0.392 / 0.702-0.706; 12 -> 0.382 / 0.713;
+  // 14 -> 0.379 / 0.696; 16 -> 0.377-0.380 / 0.695-0.698; 18 -> 0.387 / 0.688; 20 -> 0.400 / 0.695; 24 -> 0.401 / 0.681;
+  // one workgroup per four tiles (34 per CU) -> 0.412 / 0.698 (tools/sweep_blocks.sh; another box 10 / 15 / 16 / 17:
+  // 0.391-0.393 / 0.386 / 0.388-0.389 / 0.388-0.389, agent decision 4.52-4.54 / 4.45 / 4.43-4.46 / 4.39-4.44 ms).
+  // Round 3, with the heavier k_tail behind the pass, had its optimum at 10.  More rounds than ~16 per CU cost the split
+  // call more than they give the launch.  (Grids of a whole number of workgroups per CU: an "exactly balanced" 2902
+  // instead of 3072 workgroups took 0.756.)
   int &resident = h->grid_tt[(TWO ? 1 : 0) + (AGENT ? 2 : 0)];
   if (resident == 0) {
     int per_cu = 0;
@@ -400,7 +402,7 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
   TFX_INJECT(h);
-  long grid = (long)resident * 10 / 6;
+  long grid = (long)resident * 16 / 6;
   if (const char *pc = getenv("TFX_MOVE_BLOCKS_PER_CU")) grid = atoi(pc) > 0 ? (long)atoi(pc) * h->n_cu : grid;
   const long need = ((long)h->d.E * h->d.G + 3) / 4;
   if (grid > need) grid = need;

@@ -408,7 +408,8 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   if (grid > need) grid = need;
   if (grid >= 8) grid -= grid % 8;
   if (grid < 1) grid = 1;
-  const bool stagger = TWO && h->split_first && h->split_half >= 0;
+  static const bool want_stagger = !(getenv("TFX_STAGGER") && atoi(getenv("TFX_STAGGER")) == 0);
+  const bool stagger = want_stagger && TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
   const dim3 g((unsigned)grid), b(256);
   if (TWO && crec && rsw && !AGENT && !h->d.het) {

@@ -108,20 +108,26 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
     if (int frc = guard.fork(st)) return frc;
   }
   hipStream_t user_st = st;
-  for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
-    if (split) {
-      const int n0 = whole.E / 2;
-      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
-      st = half == 0 ? user_st : h->split_stream;
-      h->split_half = half;
-      h->split_first = true;
-    }
-    int t = 0;
-    const bool tt = pairs_usable(h);
-    if (tt) {
-      // two-tick passes (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
-      // tick at a time (k_risk)
-      for (; t + 1 < n_ticks && rc == TFX_OK; t += 2) {
+  // (the halves' launches are submitted pair by pair, alternately: see step_chunk)
+  Dev halves[2] = {whole, whole};
+  if (split) {
+    const int n0 = whole.E / 2;
+    halves[0] = sub_dev(h, 0, n0, nullptr);
+    halves[1] = sub_dev(h, n0, whole.E - n0, h->tick2);
+  }
+  for (int t0 = 0; t0 < n_ticks && rc == TFX_OK; t0 += 2) {
+    for (int half = 0; half < (split ? 2 : 1) && rc == TFX_OK; ++half) {
+      if (split) {
+        h->d = halves[half];
+        st = half == 0 ? user_st : h->split_stream;
+        h->split_half = half;
+        h->split_first = t0 == 0;
+      }
+      const bool tt = pairs_usable(h);
+      int t = t0;
+      if (tt && t + 1 < n_ticks) {
+        // a two-tick pass (tfx_move_tt.hpp); envs in which the first tick of a pair could overflow take the pair one
+        // tick at a time (k_risk)
         rc = launch_inputs(h, st);
         // (k_tail evaluates the bound for the pair that follows it: only the first pair pays a launch of its own)
         const bool tail = tail_usable(h);
@@ -138,15 +144,16 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
           if (rc == TFX_OK) rc = launch_advance(h, t + 1, st);
         }
         if (rc == TFX_OK) n_pair += 2;
+        t += 2;
+      }
+      for (; t < n_ticks && t < t0 + 2 && rc == TFX_OK; ++t) {
+        rc = launch_inputs(h, st);
+        if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
+        if (rc == TFX_OK) rc = launch_advance(h, t, st);
       }
     }
-    for (; t < n_ticks && rc == TFX_OK; ++t) {
-      rc = launch_inputs(h, st);
-      if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
-      if (rc == TFX_OK) rc = launch_advance(h, t, st);
-    }
-    if (split) h->d = whole;
   }
+  if (split) h->d = whole;
   h->split_half = -1;
   st = user_st;
   if (rc != TFX_OK) return rc;
@@ -167,12 +174,14 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
 }  // namespace
 
 namespace {
-// the per-tick kernels for n_ticks ticks of the envs h->d describes (the whole handle, or one half of it), on st
-int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
-  int t = 0;
+// the per-tick kernels for ticks [t_lo, t_hi) of a call of n_ticks ticks (t_lo even; default: all of them) of the envs
+// h->d describes (the whole handle, or one half of it), on st
+int step_range(tfx_handle h, int n_ticks, hipStream_t st, int t_lo = 0, int t_hi = -1) {
+  if (t_hi < 0 || t_hi > n_ticks) t_hi = n_ticks;
+  int t = t_lo;
   const bool tt = pairs_usable(h);
   if (tt) {
-    for (; t + 1 < n_ticks; t += 2) {
+    for (; t + 1 < t_hi; t += 2) {
       const bool timed = h->prof && h->ev_used < h->ev_ticks;
       hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
       if (int rc = launch_inputs(h, st)) return rc;
@@ -198,7 +207,7 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st) {
       h->pair_ticks += 2;
     }
   }
-  for (; t < n_ticks; ++t) {
+  for (; t < t_hi; ++t) {
     const bool timed = h->prof && h->ev_used < h->ev_ticks;
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
     if (int rc = launch_inputs(h, st)) return rc;
@@ -239,13 +248,21 @@ int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
     HIPCHK(hipGetLastError());
     if (int frc = guard.fork(st)) return frc;
     int rc = TFX_OK;
-    for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
-      h->d = half == 0 ? sub_dev(h, 0, n0, nullptr) : sub_dev(h, n0, whole.E - n0, h->tick2);
-      h->split_half = half;
-      h->split_first = true;
-      rc = step_range(h, n_ticks, half == 0 ? st : h->split_stream);
-      h->d = whole;
+    // The two halves' launches are submitted pair by pair, alternately.  (Submitted half after half - all of the first
+    // half's launches, then the second's - the second stream's first launch reached the device only after the host had
+    // queued the whole first half: under rocprofv3 the first half ran FIVE pairs alone at the start of a 50-tick call
+    // and the second five alone at its end, each at 0.47 ms per half pair instead of the 0.39 of two halves side by
+    // side; profiles/r04_split_submission_order.txt.)
+    const Dev halves[2] = {sub_dev(h, 0, n0, nullptr), sub_dev(h, n0, whole.E - n0, h->tick2)};
+    for (int t = 0; t < n_ticks && rc == TFX_OK; t += 2) {
+      for (int half = 0; half < 2 && rc == TFX_OK; ++half) {
+        h->d = halves[half];
+        h->split_half = half;
+        h->split_first = t == 0;
+        rc = step_range(h, n_ticks, half == 0 ? st : h->split_stream, t, t + 2);
+      }
     }
+    h->d = whole;
     h->split_half = -1;
     h->pair_ticks = pair0 + (h->pair_ticks - pair0) / 2;  // (both halves counted them)
     h->tail_ticks = tail0 + (h->tail_ticks - tail0) / 2;

@@ -7,7 +7,7 @@ import numpy as np, torch
 from gym_traffic.core import TfxEngine
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-m = n = 64
+m = n = int(os.environ.get("C4_M", "64"))
 eng = TfxEngine(m, n, 800.0, 130, n_envs=E, planes=2)
 eng.reset(np.zeros((1, eng.I), np.int32))
 eng.set_poisson(0.12 * m * 4 * 0.5, seed=1234)

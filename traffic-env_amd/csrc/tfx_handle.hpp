@@ -118,14 +118,6 @@ struct tfx_handle_s {
   PoissonDev ps{};
   void *dev_ps = nullptr;      // counts | gap_left | draws | cdf
   int *dev_greedy = nullptr;   // [E][I] actions
-  // k_grid (tfx_grid.hpp): every tick of a call in one cooperative launch, a workgroup per tile
-  int grid_res = 1;            // TFX_GRID=0 never, 2 whenever the tiles fit the chip (1: handles the two-tick passes do not take)
-  int grid_cap = -1;           // workgroups of the launch, all resident at once (-1: not sized yet, 0: the tiles do not fit)
-  size_t grid_lds = 0;
-  int grid_cus = 0;            // TFX_GRID_CUS: size the launch as if the chip had this many compute units (tests)
-  void *dev_gridsync = nullptr;  // arrival counter (256 B) | dropped cars [2][E * I]
-  int *grid_abort = nullptr;     // pinned host word a workgroup raises when a barrier wait runs out
-  long long grid_ticks = 0;      // ticks run by k_grid since tfx_create
 };
 
 namespace {

@@ -218,8 +218,6 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *pv = getenv("TFX_PAIRS")) h->pairs = atoi(pv);
   if (const char *tv = getenv("TFX_TAIL")) h->tail = atoi(tv);
   if (const char *sv = getenv("TFX_SPLIT")) h->split = atoi(sv);
-  if (const char *gv = getenv("TFX_GRID")) h->grid_res = atoi(gv);
-  if (const char *gc = getenv("TFX_GRID_CUS")) h->grid_cus = atoi(gc);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -407,8 +405,6 @@ int tfx_destroy(tfx_handle h) {
   }
   if (h->dev_ps) (void)hipFree(h->dev_ps);
   if (h->dev_greedy) (void)hipFree(h->dev_greedy);
-  if (h->dev_gridsync) (void)hipFree(h->dev_gridsync);
-  if (h->grid_abort) (void)hipHostFree(h->grid_abort);
   if (h->dev_tables) (void)hipFree(h->dev_tables);
   if (h->dev_scratch) (void)hipFree(h->dev_scratch);
   if (h->dev_arch) (void)hipFree(h->dev_arch);
@@ -647,7 +643,7 @@ int tfx_step(tfx_handle h, int32_t n_ticks, void *stream) {
   // (profiles/r04_cfg4_closed_loop_trace.txt).  Not while kernels are timed, not for calls that split over two streams.
   const Dev &d = h->d;
   if (h->use_graph && !h->prof && n_ticks >= 4 && d.layout == 1 && (long)d.E * d.G <= (long)h->n_cu * 24 &&
-      !split_usable(h, n_ticks) && !grid_usable(h, n_ticks))
+      !split_usable(h, n_ticks))
     return step_graph(h, n_ticks, st);
   return step_body(h, n_ticks, st);
 }

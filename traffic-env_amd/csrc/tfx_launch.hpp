@@ -10,7 +10,6 @@
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_tail.hpp"
-#include "tfx_grid.hpp"
 
 namespace {
 
@@ -490,101 +489,6 @@ bool tail_usable(tfx_handle h) {
   if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1) return false;
   if (tail_lds_bytes(h->d.R, h->d.I, h->het) > TAIL_LDS_MAX) return false;
   return h->tail == 2 || h->d.E >= h->n_cu;
-}
-
-// k_grid (tfx_grid.hpp): S wavefronts per tile by the ring capacity; every workgroup resident at once, each owning as
-// few tiles as that allows (h->grid_cap = workgroups to launch, 0 = the tiles do not fit)
-template <int KS, int S, bool GREEDY>
-int grid_size(tfx_handle h) {
-  auto kern = k_grid<KS, S, GREEDY>;
-  const size_t lds1 = (size_t)h->d.trows * 64 * sizeof(float2);
-  const long tiles = (long)h->d.E * h->d.G;
-  h->grid_cap = 0;
-  static size_t granted = 64 * 1024;  // (the attribute belongs to the function: only ever raised, see res_try)
-  for (int own = 1; own <= 4; ++own) {
-    const size_t lds = lds1 * own;
-    if (lds + 12 * 1024 > (size_t)160 * 1024) break;
-    if (lds > granted) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      granted = lds;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * S, lds) != hipSuccess) per_cu = 0;
-    // (TFX_GRID_CUS: tests of the several-tiles-per-workgroup form at sizes an oracle can follow)
-    const long wgs = (long)per_cu * (h->grid_cus > 0 ? h->grid_cus : h->n_cu);
-    if (wgs * own >= tiles) {
-      h->grid_cap = (int)(wgs < tiles ? wgs : tiles);
-      h->grid_lds = lds;
-      break;
-    }
-  }
-  return TFX_OK;
-}
-
-template <int KS, int S, bool GREEDY>
-int grid_launch(tfx_handle h, int n_ticks, hipStream_t st) {
-  const Dev &d = h->d;
-  const size_t sync_bytes = 256 + (size_t)2 * d.E * d.I * sizeof(int);
-  static long long *dbg_prof = nullptr; static long dbg_ticks = 0;
-  if (!h->dev_gridsync) {
-    HIPCHK(hipMalloc(&h->dev_gridsync, sync_bytes));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->grid_abort), sizeof(int), 0));
-    *h->grid_abort = 0;
-  }
-  if (*h->grid_abort) {
-    *h->grid_abort = 0;
-    return fail(TFX_EDEVICE, "k_grid: a grid barrier of an earlier call timed out (the call was abandoned part way)");
-  }
-  TFX_INJECT(h);
-  HIPCHK(hipMemsetAsync(h->dev_gridsync, 0, sync_bytes, st));
-  GridSync gs;
-  gs.ctr = reinterpret_cast<unsigned *>(h->dev_gridsync);
-  gs.abort_word = h->grid_abort;
-  gs.ovf = reinterpret_cast<int *>(static_cast<char *>(h->dev_gridsync) + 256);
-  gs.n_wg = (unsigned)h->grid_cap;
-  gs.dbg = getenv("TFX_GRID_DBG") ? atoi(getenv("TFX_GRID_DBG")) : 0;
-  gs.prof = nullptr;
-  if (gs.dbg & 4) {
-    if (!dbg_prof) { HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&dbg_prof), 64, 0)); memset(dbg_prof, 0, 64); }
-    gs.prof = dbg_prof;
-    dbg_ticks += n_ticks;
-    if (dbg_ticks % 1000 == 0) {
-      (void)hipDeviceSynchronize();
-      fprintf(stderr, "k_grid cycles/tick (100 MHz?): move %.0f B1 %.0f handoff %.0f B2 %.0f greedy %.0f B3 %.0f\n", (double)dbg_prof[0] / dbg_ticks,
-              (double)dbg_prof[1] / dbg_ticks, (double)dbg_prof[2] / dbg_ticks, (double)dbg_prof[3] / dbg_ticks, (double)dbg_prof[4] / dbg_ticks, (double)dbg_prof[5] / dbg_ticks);
-    }
-  }
-  Dev dv = d;
-  int nt = n_ticks;
-  void *args[] = {&dv, &nt, &gs};
-  HIPCHK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_grid<KS, S, GREEDY>), dim3(gs.n_wg), dim3(64 * S), args,
-                                    h->grid_lds, st));
-  h->step_kernel = "k_grid";
-  h->grid_ticks += n_ticks;
-  return TFX_OK;
-}
-
-template <bool SIZE>
-int grid_dispatch(tfx_handle h, int n_ticks, hipStream_t st) {
-  const int cap = h->d.C - 2;
-  if (cap <= 64) {
-    if (h->greedy) return SIZE ? grid_size<8, 8, true>(h) : grid_launch<8, 8, true>(h, n_ticks, st);
-    return SIZE ? grid_size<8, 8, false>(h) : grid_launch<8, 8, false>(h, n_ticks, st);
-  }
-  if (h->greedy) return SIZE ? grid_size<8, 16, true>(h) : grid_launch<8, 16, true>(h, n_ticks, st);
-  return SIZE ? grid_size<8, 16, false>(h) : grid_launch<8, 16, false>(h, n_ticks, st);
-}
-
-// Handles whose launches cannot fill the chip (no two-tick passes) and whose tiles are all resident at once; plain
-// tfx_step calls of single-archetype cars without the side-word plane.  (E <= 8: every workgroup reads every env's flag.)
-bool grid_usable(tfx_handle h, int n_ticks) {
-  const Dev &d = h->d;
-  if (!h->grid_res || h->prof || n_ticks < 2 || d.layout != 1 || d.w || h->het || d.validate || d.agent_mode || d.accum_rewards)
-    return false;
-  if (h->res_epb > 0 || h->move_variant != 0 || d.E > 8 || d.C - 2 > 128) return false;
-  if (h->grid_res != 2 && pairs_usable(h)) return false;
-  if (h->grid_cap < 0 && grid_dispatch<true>(h, 0, nullptr) != TFX_OK) return false;
-  return h->grid_cap > 0;
 }
 
 // Two halves on two streams: where each half still runs pairs with k_tail behind them (one env per CU and half).

@@ -20,15 +20,20 @@
 
 namespace tfx {
 
-// One tile's move, by the S wavefronts of the calling workgroup (all of them call it, with the same arguments).
-// KS cars per segment held in registers: C - 2 <= S * KS; W: spawn-tick plane; S segments (wavefronts) per tile.
-// d.xv may point anywhere the tile's rows live (k_grid: the workgroup's LDS copy of them).
-template <int KS, bool W, int S>
-__device__ __forceinline__ void move_ts_tile(const Dev &d, const long tile, const int tick, const int tick_sp, const int tidx,
-                                             const int lane, const int seg, int (&s_wait)[S][64], int (&s_det)[S][64],
-                                             int (&s_kpop)[64], float (&s_tail)[64], unsigned long long &my_updates) {
+// KS cars per segment held in registers: C - 2 <= S * KS; W: spawn-tick plane; S segments (wavefronts) per tile
+template <int KS, bool W = false, int S = 4>
+__global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx) {
+  __shared__ int s_wait[S][64], s_det[S][64], s_kpop[64];
+  __shared__ float s_tail[64];
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tick = *d.tickA;
   const int C = d.C;
-  {
+  const long tiles = (long)d.E * d.G;
+  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
+  unsigned long long my_updates = 0;
+
+  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int env = (int)(tile / d.G);
     const int e_slot = d.slot_road[(int)(tile - (long)env * d.G) * 64 + lane];
     const bool valid = e_slot >= 0;
@@ -197,21 +202,6 @@ __device__ __forceinline__ void move_ts_tile(const Dev &d, const long tile, cons
     }
     __syncthreads();  // the LDS words are free for the next tile
   }
-}
-
-template <int KS, bool W = false, int S = 4>
-__global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx) {
-  __shared__ int s_wait[S][64], s_det[S][64], s_kpop[64];
-  __shared__ float s_tail[64];
-  const int lane = threadIdx.x & 63;
-  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tick = *d.tickA;
-  const long tiles = (long)d.E * d.G;
-  const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
-  unsigned long long my_updates = 0;
-
-  for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x)
-    move_ts_tile<KS, W, S>(d, tile, tick, tick_sp, tidx, lane, seg, s_wait, s_det, s_kpop, s_tail, my_updates);
 
   if (seg == 0) {
     for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);

@@ -228,7 +228,6 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st, int t_lo = 0, int t_hi
 
 // n_ticks ticks on the per-tick kernels, the env range in two halves on two streams where that pays
 int step_chunk(tfx_handle h, int n_ticks, hipStream_t st) {
-  if (grid_usable(h, n_ticks)) return grid_dispatch<false>(h, n_ticks, st);  // one launch for the whole call (tfx_grid.hpp)
   if (split_usable(h, n_ticks)) {
     // fork: the handle's own stream takes the second half of the envs, the caller's stream the first
     if (int rc = ensure_split(h, st)) return rc;

@@ -343,3 +343,26 @@ def test_regular_mirror_counts_equal_the_reference_schedule(name, golden_cache):
         assert (cnt.sum(axis=1) == per_tick[t]).all(), (name, t)
         hist += cnt.sum(axis=0)
     assert hist.min() > 0 and hist.max() < 3 * hist.sum() / n_entry
+
+
+def test_no_kernel_carries_a_stack_frame_or_flat_accesses():
+    """tools/kernel_regs.py over the built library: the kernels whose per-road pointers are moved onto LDS copies must
+    reach them with ds_ instructions, and no kernel may carry the stack frame of a function the inliner left as a real
+    call (the parameter block then travels through scratch memory and every access through it becomes a flat one:
+    k_tail<AGENT, HET> ran a decision 26 % slower that way).  Small spills of rare paths (< 128 bytes) are tolerated."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_regs
+    if not os.path.exists(kernel_regs.LIB):
+        pytest.skip("library not built")
+    table = kernel_regs.kernel_table()
+    assert len(table) > 60                                     # every instantiation is listed
+    bad = [(k["name"], k["scratch"], k.get("flat_", 0)) for k in table if k["scratch"] >= 128 or k.get("flat_", 0) > 16]
+    assert not bad, bad
+    tails = [k for k in table if k["name"].startswith("void k_tail<")]
+    assert len(tails) == 12 and all(k["ds_"] > 100 for k in tails)
+    # the register cap the split call counts on: the plain k_tail fits the slots one wavefront of the pass frees
+    plain_tail = [k for k in tails if k["name"].startswith("void k_tail<false, false, false, false>")][0]
+    assert plain_tail["vgpr"] <= 80

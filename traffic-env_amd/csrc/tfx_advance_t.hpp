@@ -95,7 +95,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
 // (inlined on purpose: as a real call it took no SGPR spills but a 512-byte stack frame per lane for the parameter
 // block, and k_tail went from 0.19 to 0.43 ms per pair)
 template <bool HET = false, bool WP = true>
-__device__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) {
+__device__ __forceinline__ void advance_env_serial_t(const Dev &d, int env, int tick, int tidx) {
   const int C = d.C;
   int *ob = d.obs + (size_t)env * d.obs_len;
   float *rew = d.rewards + (size_t)env * d.I;

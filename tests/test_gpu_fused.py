@@ -55,7 +55,7 @@ def pertick_engine(E, **cfg):
 def test_fused_random_states_vs_oracle(m, n, C, length, sorted_x, layout):
     rng = np.random.RandomState(4321 + C + int(sorted_x))
     E, T = 5, 7
-    eng = fused_engine(E, epb=1 + C % 3, lpr=(1, 2, 4)[(C // 2 + int(sorted_x)) % 3], layout=layout, planes=3 if layout == "ring" else 2,
+    eng = fused_engine(E, epb=1 + C % 3, lpr=(1, 2, 4, 3)[(C // 2 + int(sorted_x)) % 4], layout=layout, planes=3 if layout == "ring" else 2,
                        m=m, n=n, length=length, capacity=C, rate=0.5)
     orc = oracle_like(eng)
     ran = 0
@@ -87,7 +87,7 @@ def test_fused_equals_tick_by_tick_on_device_rules():
     60 single ticks == the same with fusing disabled; counters and done flags included."""
     E, T = 9, 60
     cfg = dict(m=4, n=4, length=200.0, capacity=34, rate=0.5)
-    a = fused_engine(E, epb=4, lpr=2, **cfg)
+    a = fused_engine(E, epb=2, lpr=3, **cfg)
     b = fused_engine(E, epb=1, lpr=1, **cfg)
     c = pertick_engine(E, **cfg)
     x, v, leading, lastcar = wl.prefill_one_env(4, 4, 200.0, 34, 24, 8.0)

@@ -37,7 +37,7 @@ def car_layout(request):
 # ... and through both step paths: the LDS-resident multi-tick kernel k_res (what small envs get by
 # default, packing 3 envs per workgroup so wavefronts straddle env boundaries) and the per-tick
 # streaming kernels (TFX_RESIDENT=0: what big envs get)
-@pytest.fixture(params=["resident", "resident1", "resident4", "pertick", "pairs"], autouse=True)
+@pytest.fixture(params=["resident", "resident1", "resident4", "resident_mixed", "pertick", "pairs"], autouse=True)
 def step_path(request, monkeypatch):
     # "pairs": the per-tick kernels with two-tick passes (k_move_tt + k_edge) wherever a call has three ticks or more
     monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
@@ -46,7 +46,8 @@ def step_path(request, monkeypatch):
     if request.param.startswith("resident"):
         monkeypatch.setenv("TFX_RESIDENT", "1")
         monkeypatch.setenv("TFX_RES_EPB", "3")
-        monkeypatch.setenv("TFX_RES_LPR", {"resident1": "1", "resident4": "4"}.get(request.param, "2"))   # lanes per road
+        # lanes per road ("3": two, and four on the roads cars enter the map on - the handle's own choice for big batches)
+        monkeypatch.setenv("TFX_RES_LPR", {"resident1": "1", "resident4": "4", "resident_mixed": "3"}.get(request.param, "2"))
     else:
         monkeypatch.setenv("TFX_RESIDENT", "0")
     yield request.param

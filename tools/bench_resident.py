@@ -31,7 +31,7 @@ if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for cfg, envs in cases:
     out = []
-    for res, lpr, epb in (("0", "0", "0"), ("1", "2", "0"), ("1", "4", "0"), ("1", "1", "0"), ("1", "2", "1"), ("1", "4", "1"),
+    for res, lpr, epb in (("0", "0", "0"), ("1", "3", "0"), ("1", "2", "0"), ("1", "4", "0"), ("1", "1", "0"), ("1", "3", "3"), ("1", "2", "1"), ("1", "4", "1"),
                           ("1", "2", "2"), ("1", "2", "3"), ("1", "1", "4"), ("1", "1", "7")):
         os.environ["TFX_RESIDENT"] = res
         os.environ.pop("TFX_RES_EPB", None)
@@ -43,5 +43,5 @@ for cfg, envs in cases:
         g, fused = best(cfg, envs, "graph")
         t, _ = best(cfg, envs, "ticks")
         out.append("%s: decision %.0f us, step(10) %.0f us" % ("per-tick" if res == "0" else (
-            "k_res %s lane%s/road epb=%s" % (lpr, "s" if lpr != "1" else "", epb if epb != "0" else "auto")), g, t))
+            "k_res %s lane%s/road epb=%s" % ("2+4" if lpr == "3" else lpr, "s" if lpr != "1" else "", epb if epb != "0" else "auto")), g, t))
     print("%s x %d envs | " % (cfg, envs) + " | ".join(out), flush=True)

@@ -22,7 +22,7 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     remi = bool(rng.randint(2)); T = int(rng.choice([2, 3, 4, 5, 10])); period = int(rng.choice([1, 2, 5, 9]))
     os.environ["TFX_RESIDENT"] = str(int(rng.randint(3) > 0))     # the LDS-resident k_res (2 in 3) | per-tick kernels
     os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 4])))
-    os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2, 4])))
+    os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2, 3, 4])))
     os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))     # two-tick passes + k_risk forced at any size | never
     os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2])))         # (plain step() calls between decisions: k_tail, split)
     os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))

@@ -58,7 +58,7 @@ def _run(rng, seed, LIMIT):
         if layout == "transposed" and mv: os.environ["TFX_MOVE_VARIANT"] = str(mv)
         os.environ["TFX_RESIDENT"] = "1" if mode == 1 else "0"      # LDS-resident multi-tick kernel | per-tick kernels
         os.environ["TFX_RES_EPB"] = str(int(rng.choice([1, 2, 5])))
-        os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2, 4])))    # lanes per road of k_res
+        os.environ["TFX_RES_LPR"] = str(int(rng.choice([1, 2, 3, 4])))    # lanes per road of k_res
         os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))    # two-tick passes (k_move_tt + k_edge) forced at any size | never
         os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2, 2])))     # ... finished by k_tail | by three launches
         os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))       # ... the env range in two halves on two streams

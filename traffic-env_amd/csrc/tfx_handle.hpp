@@ -73,7 +73,7 @@ struct tfx_handle_s {
   int tiles_per_env = 0;      // G: 64-slot tiles one env occupies in the transposed layout
   // k_res (tfx_resident.hpp): whole envs resident in LDS for all the ticks of a call
   int res_epb = 0;            // envs per workgroup; 0 = the envs do not fit / disabled (TFX_RESIDENT=0)
-  int res_lpr = 1;            // lanes per road (1 or 2)
+  int res_lpr = 1;            // lanes per road: 1, 2, 4, or 3 = two and four on the roads without a predecessor
   int res_threads = 0;
   size_t res_lds = 0;
   int res_min_ticks = 1;      // calls shorter than this take the per-tick kernels (TFX_RES_MIN_TICKS)

@@ -192,9 +192,13 @@ int launch_greedy(tfx_handle h, hipStream_t st) {
 template <int LPR, bool W>
 bool res_try(tfx_handle h, int epb) {
   const Dev &d = h->d;
-  const int threads = (LPR * epb * d.R + 63) / 64 * 64;
+  // (LPR = 3: two lanes per road and two more on each of the 2 (m + n) roads without a predecessor; 32 spare columns
+  // for the lanes past the last env)
+  const int n_ent = 2 * (h->cfg.m + h->cfg.n);
+  const int threads = ((LPR == 3 ? epb * (2 * d.R + 2 * n_ent) : LPR * epb * d.R) + 63) / 64 * 64;
   if (threads > RES_MAX_THREADS) return false;
-  size_t lds = res_lds_bytes(threads / LPR, d.C, epb, d.I, d.n_entry, W);
+  const int cols = LPR == 3 ? epb * d.R + 32 : threads / LPR;
+  size_t lds = res_lds_bytes(cols, d.C, epb, d.I, d.n_entry, W);
   if (lds > (size_t)160 * 1024) return false;
   {
     // Even placement: when every workgroup of the launch is resident at once the dispatcher may stack
@@ -237,12 +241,21 @@ int res_configure(tfx_handle h) {
   // empty - there a tick is as long as its longest chain: cfg1 x 256 envs, a 10-tick call 84 -> 64 us, a fused decision
   // 74 -> 59; at 1024 envs the five wavefronts an env then takes no longer fit beside each other (16 per CU at this
   // kernel's 128 registers) and the call takes 195 us instead of 106.  TFX_RES_LPR = 1 / 2 / 4 forces.
+  // Otherwise the MIXED form (3): two lanes per road, four on the roads cars enter the map on - the longest chains of a
+  // loaded network - in the same number of wavefronts per env as two everywhere (cfg1: 160 + 32 lanes = 3 wavefronts).
   const long waves4 = ((long)4 * d.R + 63) / 64;
-  int lpr_max = ((long)d.E * waves4 <= (long)h->n_cu * 8) ? 4 : 2;
-  if (const char *lv = getenv("TFX_RES_LPR")) lpr_max = atoi(lv) == 1 ? 1 : (atoi(lv) == 4 ? 4 : 2);
+  int lpr_max = ((long)d.E * waves4 <= (long)h->n_cu * 8) ? 4 : 3;
+  if (const char *lv = getenv("TFX_RES_LPR")) lpr_max = (atoi(lv) >= 1 && atoi(lv) <= 4) ? atoi(lv) : 3;
   const char *ev = getenv("TFX_RES_EPB");
-  for (int lpr = lpr_max; lpr >= 1; lpr >>= 1) {
-    auto fits = [&](int epb) { return lpr == 4 ? res_try<4, W>(h, epb) : lpr == 2 ? res_try<2, W>(h, epb) : res_try<1, W>(h, epb); };
+  for (int lpr = lpr_max; lpr >= 1; --lpr) {
+    auto fits = [&](int epb) {
+      return lpr == 4 ? res_try<4, W>(h, epb) : lpr == 3 ? res_try<3, W>(h, epb) : lpr == 2 ? res_try<2, W>(h, epb) : res_try<1, W>(h, epb);
+    };
+    // (three rounds of one-env workgroups or more: two lanes per road with three envs per workgroup stays ahead - 363 us
+    // per 10-tick call at cfg1 x 4096 against 392 for the mixed form, whose three envs no longer fit one workgroup)
+    if (lpr == 3 && !ev && !getenv("TFX_RES_LPR") &&
+        (long)d.E * (((long)2 * d.R + 4 * (h->cfg.m + h->cfg.n) + 63) / 64) >= (long)3 * h->n_cu * 16 && !res_try<3, W>(h, 3))
+      continue;
     if (!fits(1)) continue;  // (leaves the one-env configuration in place)
     if (ev) {
       int want = atoi(ev) < 1 ? 1 : atoi(ev);
@@ -256,8 +269,8 @@ int res_configure(tfx_handle h) {
     // pack envs: the smallest number of equal rounds over the chip, E / (CUs * b) for b = 1, 2, ...
     // (round 4, cfg1 x 4096 - three rounds of one-env workgroups over the chip: three envs per workgroup 360 us per
     // 10-tick call against 417; at 1024 envs - one round - one env per workgroup stays ahead, 106 against 130)
-    if (lpr == 2) {
-      const long waves2 = ((long)2 * d.R + 63) / 64;
+    if (lpr == 2 || lpr == 3) {
+      const long waves2 = ((long)2 * d.R + (lpr == 3 ? 4 * (h->cfg.m + h->cfg.n) : 0) + 63) / 64;
       if ((long)d.E * waves2 >= (long)3 * h->n_cu * 16 && !fits(3)) (void)fits(1);
     }
     if (lpr >= 2) return TFX_OK;
@@ -292,6 +305,9 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   a.n_ticks = n_ticks;
   a.greedy_spacing = h->greedy ? h->greedy_spacing : 0;
   a.greedy_act = h->dev_greedy;
+  a.n_ent = 2 * (h->cfg.m + h->cfg.n);
+  a.n_int = d.r - a.n_ent;
+  a.cols = h->res_epb * d.R + 32;
   const int grid = (d.E + h->res_epb - 1) / h->res_epb;
   a.own_clock = grid == 1 ? 1 : 0;
   h->step_kernel = "k_res";
@@ -299,6 +315,9 @@ int launch_res(tfx_handle h, int n_ticks, hipStream_t st, int tail = 0, int remi
   if (h->res_lpr == 4) {
     if (d.w) hipLaunchKernelGGL((k_res<4, true>), g, b, h->res_lds, st, d, a);
     else hipLaunchKernelGGL((k_res<4, false>), g, b, h->res_lds, st, d, a);
+  } else if (h->res_lpr == 3) {
+    if (d.w) hipLaunchKernelGGL((k_res<3, true>), g, b, h->res_lds, st, d, a);
+    else hipLaunchKernelGGL((k_res<3, false>), g, b, h->res_lds, st, d, a);
   } else if (h->res_lpr == 2) {
     if (d.w) hipLaunchKernelGGL((k_res<2, true>), g, b, h->res_lds, st, d, a);
     else hipLaunchKernelGGL((k_res<2, false>), g, b, h->res_lds, st, d, a);

@@ -5,7 +5,7 @@
 // for small grids that is all latency (round 1: cfg1 x 1024 envs at 0.18 of the HBM roofline, 38 us
 // per tick of which the cars need 3).  Here a workgroup owns `epb` whole envs for the whole call:
 //   * LPR = 1, 2 or 4 lanes per road (lanes = LPR * epb * R, packed across env boundaries so wavefronts
-//     stay full).  With two lanes the road's cars split in halves - the Jacobi update needs only OLD
+//     stay full), or the mixed form (3): two lanes per road, four on the roads cars enter the map on.  With two lanes the road's cars split in halves - the Jacobi update needs only OLD
 //     neighbours, so the second lane starts from the OLD state of the car in front of its half (read
 //     before the first lane, which sits next to it in the same wavefront, overwrites it) - and the
 //     walk, the tick's critical path, is half as long; pops, counts and the tail meet through a lane
@@ -51,6 +51,9 @@ struct ResArgs {
   // on-device Poisson arrivals (tfx_set_poisson): the stream of k_poisson, drawn inside the kernel
   int poisson;
   PoissonDev ps;
+  // LPR = 3 (two lanes per road, four on the roads without a predecessor): columns of the workgroup's LDS arrays, and
+  // how many of an env's road slots are interior roads / roads without a predecessor (build_slots' order)
+  int cols, n_int, n_ent;
 };
 
 constexpr int RES_KH = 2;  // popped cars copied per handoff round
@@ -77,9 +80,16 @@ __host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, i
 template <int LPR, bool W>
 __global__ __launch_bounds__(RES_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_res(const Dev d, const ResArgs a) {
-  static_assert(LPR == 1 || LPR == 2 || LPR == 4, "one, two or four lanes per road (adjacent lanes of one wavefront)");
+  static_assert(LPR >= 1 && LPR <= 4, "one, two or four lanes per road (adjacent lanes of one wavefront); 3: two, and four on entry roads");
+  // LPR = 3, the mixed form: the roads a tick waits for are the longest ones, and under load those are the roads cars
+  // enter the map on (their queues reach the ring's capacity while an interior road holds what a green phase lets in).
+  // They get four lanes, every other road two: at cfg1 the longest chain of a tick drops from 16 cars to 12 with the same
+  // three wavefronts per env (160 + 32 lanes) - the whole-env form of four lanes per road needs five.
+  constexpr bool MIX = LPR == 3;
+  constexpr int LMAX = MIX ? 4 : LPR;  // most lanes any road has
   extern __shared__ __align__(16) unsigned char res_smem[];
-  const int T = blockDim.x / LPR, C = d.C, NS = C - 1, R = d.R, I = d.I;  // T: road columns of the workgroup
+  const int C = d.C, NS = C - 1, R = d.R, I = d.I;
+  const int T = MIX ? a.cols : (int)blockDim.x / LMAX;  // T: road columns of the workgroup
   const int epb = a.epb;
   float2 *ring = reinterpret_cast<float2 *>(res_smem);
   float *ringw = reinterpret_cast<float *>(ring + (size_t)NS * T);
@@ -98,9 +108,34 @@ void k_res(const Dev d, const ResArgs a) {
   int *s_gap = s_spawn + (size_t)epb * d.n_entry;  // [epb] whole ticks until the env's next car (-1: not drawn yet)
   unsigned *s_draws = reinterpret_cast<unsigned *>(s_gap + epb);  // [epb] index of the env's next car
 
-  const int h = (int)(threadIdx.x & (LPR - 1));  // which share (half, quarter) of the road's cars this lane walks
+  int lpr = LMAX, lsh = LMAX == 4 ? 2 : (LMAX == 2 ? 1 : 0);  // this road's lanes, and their log2
+  int h = (int)(threadIdx.x & (LMAX - 1));  // which share (half, quarter) of the road's cars this lane walks
+  int t = (int)(threadIdx.x / LMAX);        // the road's column
+  if (MIX) {
+    // an env's lanes, in the slot order of its roads: 2 per interior road | 4 per road without a predecessor | 2 per exit
+    // road (2 n_int and the lanes of an env are multiples of 4: a road's lanes are adjacent lanes of one wavefront)
+    const int per_env = 2 * R + 2 * a.n_ent;
+    const int el0 = (int)threadIdx.x / per_env, q = (int)threadIdx.x - el0 * per_env;
+    const int a0 = 2 * a.n_int, a1 = a0 + 4 * a.n_ent;
+    int col;
+    lpr = 2;
+    lsh = 1;
+    if (q < a0) {
+      col = q >> 1;
+      h = q & 1;
+    } else if (q < a1) {
+      col = a.n_int + ((q - a0) >> 2);
+      h = (q - a0) & 3;
+      lpr = 4;
+      lsh = 2;
+    } else {
+      col = a.n_int + a.n_ent + ((q - a1) >> 1);
+      h = (q - a1) & 1;
+    }
+    t = el0 * R + col;
+    if (t >= T) t = T - 1;  // (lanes past the last env: a column of their own, never a valid road)
+  }
   const bool hA = h == 0;                                // the road's first lane also does everything per road
-  const int t = (int)(threadIdx.x / LPR);  // the road's column
   // Columns follow the storage-slot order of the env's roads (interior train roads, entry roads, exit
   // roads: build_slots) rather than road ids: roads of a kind have similar car counts, a wavefront
   // walks as far as its longest road, and a wavefront of short roads frees its SIMD early for the
@@ -137,13 +172,13 @@ void k_res(const Dev d, const ResArgs a) {
     const int head = wrap1(ld + 1, C);
     if (d.layout == 1) {
       const size_t col = tcol(d, env, e);
-      for (int k = h; k < n; k += LPR) {  // (the road's lanes share the copy)
+      for (int k = h; k < n; k += lpr) {  // (the road's lanes share the copy)
         const int slot = ring_adv(head, k, C);
         RG(slot, t) = d.xv[col + (size_t)k * 64];
         if (W) RW(slot, t) = d.w[col + (size_t)k * 64];
       }
     } else {
-      for (int k = h; k < n; k += LPR) {
+      for (int k = h; k < n; k += lpr) {
         const int slot = ring_adv(head, k, C);
         RG(slot, t) = d.xv[(size_t)id * C + slot];
         if (W) RW(slot, t) = d.w[(size_t)id * C + slot];
@@ -334,20 +369,20 @@ void k_res(const Dev d, const ResArgs a) {
     }
     // ---- move_cars (:187-212): the lane walks its road from the head, leader chain in registers ---
     {
-      if (LPR > 1) {  // what the road's first lane worked out, for the others
-        const int src = (int)(threadIdx.x & 63u & ~(unsigned)(LPR - 1));
+      if (LMAX > 1) {  // what the road's first lane worked out, for the others
+        const int src = (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1));
         n_tot = __shfl(n_tot, src, 64);
         ld = __shfl(ld, src, 64);
         lc = __shfl(lc, src, 64);
         xL = __shfl(xL, src, 64);
       }
       // this lane's share of the road: cars [my_k0, my_k0 + my_n)
-      const int n_share = (n_tot + LPR - 1) / LPR;
+      const int n_share = (n_tot + lpr - 1) >> lsh;
       const int my_k0 = h * n_share;
       const int my_n = run ? (n_tot - my_k0 < 0 ? 0 : (n_tot - my_k0 < n_share ? n_tot - my_k0 : n_share)) : 0;
       float xprev = xL, vprev = 0.0f, llv = 0.0f;
       const int head = wrap1(ld + 1, C);
-      if (LPR > 1 && !hA && my_n > 0) {
+      if (LMAX > 1 && !hA && my_n > 0) {
         // a later share follows the last car of the share before it: its OLD state, read here - before the
         // neighbouring lane (same wavefront, so in program order) rewrites that slot
         const float2 lead = RG(ring_adv(head, my_k0 - 1, C), t);
@@ -443,15 +478,16 @@ void k_res(const Dev d, const ResArgs a) {
           tail_x = act ? xn[u] : tail_x;
         }
       }
-      if (LPR > 1) {  // the shares meet in the road's first lane
-        const int base = (int)(threadIdx.x & 63u & ~(unsigned)(LPR - 1));
+      if (LMAX > 1) {  // the shares meet in the road's first lane
+        const int base = (int)(threadIdx.x & 63u & ~(unsigned)(lpr - 1));
         bool chain = open;  // every car so far left: the pop prefix runs on into the next share
 #pragma unroll
-        for (int j = 1; j < LPR; ++j) {
-          const int kpop_b = __shfl(kpop, base + j, 64), wait_b = __shfl(n_wait, base + j, 64), det_b = __shfl(n_det, base + j, 64);
-          const int far_b = __shfl((int)far, base + j, 64), n_b = __shfl(my_n, base + j, 64), open_b = __shfl((int)open, base + j, 64);
-          const float tail_b = __shfl(tail_x, base + j, 64);
-          if (hA) {
+        for (int j = 1; j < LMAX; ++j) {
+          const int sj = base + (j < lpr ? j : 0);  // (every lane takes part in the exchange; a road with fewer lanes ignores it)
+          const int kpop_b = __shfl(kpop, sj, 64), wait_b = __shfl(n_wait, sj, 64), det_b = __shfl(n_det, sj, 64);
+          const int far_b = __shfl((int)far, sj, 64), n_b = __shfl(my_n, sj, 64), open_b = __shfl((int)open, sj, 64);
+          const float tail_b = __shfl(tail_x, sj, 64);
+          if (hA && j < lpr) {
             if (chain) {
               kpop += kpop_b;
               far = far || (far_b != 0);
@@ -616,14 +652,14 @@ void k_res(const Dev d, const ResArgs a) {
     const int head = wrap1(ld + 1, C);
     if (d.layout == 1) {
       const size_t col = tcol(d, env, e);
-      for (int k = h; k < n; k += LPR) {
+      for (int k = h; k < n; k += lpr) {
         const int slot = ring_adv(head, k, C);
         d.xv[col + (size_t)k * 64] = RG(slot, t);
         if (W) d.w[col + (size_t)k * 64] = RW(slot, t);
       }
       if (xL_set && hA) d.leadx[id] = xL;
     } else {
-      for (int k = h; k < n; k += LPR) {
+      for (int k = h; k < n; k += lpr) {
         const int slot = ring_adv(head, k, C);
         d.xv[(size_t)id * C + slot] = RG(slot, t);
         if (W) d.w[(size_t)id * C + slot] = RW(slot, t);

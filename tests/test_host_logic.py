@@ -349,7 +349,8 @@ def test_no_kernel_carries_a_stack_frame_or_flat_accesses():
     """tools/kernel_regs.py over the built library: the kernels whose per-road pointers are moved onto LDS copies must
     reach them with ds_ instructions, and no kernel may carry the stack frame of a function the inliner left as a real
     call (the parameter block then travels through scratch memory and every access through it becomes a flat one:
-    k_tail<AGENT, HET> ran a decision 26 % slower that way).  Small spills of rare paths (< 128 bytes) are tolerated."""
+    k_tail<AGENT, HET> ran a decision 26 % slower that way: a 1.1 KB frame).  Register spills of the capped kernels (the
+    side-word forms at five wavefronts per SIMD: up to ~130 bytes) are tolerated."""
     import os
     import sys
     from conftest import ROOT
@@ -359,7 +360,7 @@ def test_no_kernel_carries_a_stack_frame_or_flat_accesses():
         pytest.skip("library not built")
     table = kernel_regs.kernel_table()
     assert len(table) > 60                                     # every instantiation is listed
-    bad = [(k["name"], k["scratch"], k.get("flat_", 0)) for k in table if k["scratch"] >= 128 or k.get("flat_", 0) > 16]
+    bad = [(k["name"], k["scratch"], k.get("flat_", 0)) for k in table if k["scratch"] >= 256 or k.get("flat_", 0) > 16]
     assert not bad, bad
     tails = [k for k in table if k["name"].startswith("void k_tail<")]
     assert len(tails) == 12 and all(k["ds_"] > 100 for k in tails)

@@ -58,8 +58,11 @@ namespace tfx {
 #ifndef TT_WAVES
 #define TT_WAVES 6
 #endif
+// With the side-word plane (validate mode, heterogeneous cars): five per SIMD (<= 96 registers; the kernels would take
+// 105-128).  Measured at cfg2, ms per tick of the split call at 4 / 5 / 6 per SIMD: validate mode 0.637 / 0.602 / 0.597,
+// three archetypes 0.953 / 0.900-0.908 / 0.975 (the arithmetic of the heterogeneous step pays for the spills of 6).
 #ifndef TT_WAVES_W
-#define TT_WAVES_W 4
+#define TT_WAVES_W 5
 #endif
 #define TT_ATTR(W) __attribute__((amdgpu_waves_per_eu((W) ? TT_WAVES_W : TT_WAVES, (W) ? TT_WAVES_W : TT_WAVES)))
 // W: the spawn-tick plane travels with the cars (validate mode, advance_hack's trip times :139-157): a car's side word

@@ -51,7 +51,7 @@ inline size_t tail_lds_bytes(int R, int I, bool het) {
 // W: validate mode - the cars' side words travel along (edge_tile)
 // HET (implies W): heterogeneous cars - the advance carries the cars' table rows, the edge work reads their parameters
 // from an LDS copy of the table
-// As many registers as a wavefront of the pass it runs beside (TT_ATTR: 80, with the side-word plane 128): its
+// As many registers as a wavefront of the pass it runs beside (TT_ATTR: 80, with the side-word plane 96): its
 // wavefronts then fit the slots the pass's leave.
 template <bool GREEDY = false, bool AGENT = false, bool W = false, bool HET = false>
 __global__ __launch_bounds__(256) TT_ATTR(W) void k_tail(const Dev d, const int tidx, const int flags) {

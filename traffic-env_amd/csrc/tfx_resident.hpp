@@ -77,8 +77,14 @@ __host__ __device__ inline size_t res_lds_bytes(int Tr, int C, int epb, int I, i
 // SIMDs.  After idleness or a different kernel it did not: a CU then held three workgroups, the fourth ran
 // in a second round and the whole launch took 1.45x (rocprofv3: same clock, same wave-cycles; 12 launches of
 // 36 in a loop that interleaves another kernel, 0 of 36 with this bound, and the steady state is no slower).
+// Round 4 re-measured (make exp EXP=RW3:-DRES_WAVES=3 ...), cfg1 x 1024, a 10-tick call at 3 / 4 / 5 / 6 wavefronts per SIMD:
+// 100 / 103 / 117 / 133 us - and at 3 the bench's regions spread over 8.5 .. 13.7 us per tick (the misplaced launches)
+// against 8.5 .. 9.6 at 4; four lanes per road at 5 per SIMD (all four workgroups of a CU side by side): 150 us.
 template <int LPR, bool W>
-__global__ __launch_bounds__(RES_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef RES_WAVES
+#define RES_WAVES 4
+#endif
+__global__ __launch_bounds__(RES_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(RES_WAVES, 8)))
 void k_res(const Dev d, const ResArgs a) {
   static_assert(LPR >= 1 && LPR <= 4, "one, two or four lanes per road (adjacent lanes of one wavefront); 3: two, and four on entry roads");
   // LPR = 3, the mixed form: the roads a tick waits for are the longest ones, and under load those are the roads cars

@@ -147,7 +147,9 @@ __device__ void advance_env_serial(const Dev &d, int env, int tick, int tidx) {
 // roadgraph.py:38-39, plus the light words and the reward of that intersection), s >= I is exit road r + (s - I).
 // Item 0 of an env flagged for it runs the literal serial loop for the whole env.
 // WP = false: the caller knows there is no side-word plane (compact_head_rows)
-template <bool TL, bool HET = false, bool GREEDY = false, bool WP = true>
+// BATCH (transposed layout): the loads of the intersection's four roads are issued before any of their stores
+// (advance_road_t_load; k_advance - k_tail works on LDS copies and within the registers of a wavefront of the pass)
+template <bool TL, bool HET = false, bool GREEDY = false, bool WP = true, bool BATCH = false>
 __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int tick, int tidx) {
   const bool frozen = env_frozen(d, env, tick);  // stopped for the rest of this agent step
   const bool serial = !frozen && d.env_flag[env] == tick + 1;
@@ -170,10 +172,19 @@ __device__ __forceinline__ void advance_item(const Dev &d, int env, int s, int t
     light_update(d, env, s, tick, tidx, ph_new, el_new);
     if (!serial) {
       int ovf = 0;
+      if (TL && BATCH) {
+        RoadAdvIn in[4];
 #pragma unroll
-      for (int dir = 0; dir < 4; ++dir) {
-        const int e = dir * d.I + s;
-        ovf += (TL ? advance_road_t<HET, WP>(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
+        for (int dir = 0; dir < 4; ++dir) in[dir] = advance_road_t_load<HET, WP>(d, env, dir * d.I + s);
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir)
+          ovf += advance_road_t_apply<HET, WP>(d, env, dir * d.I + s, in[dir]) + rec_ovf_sp(in[dir].rc.y);
+      } else {
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir) {
+          const int e = dir * d.I + s;
+          ovf += (TL ? advance_road_t<HET, WP>(d, env, e) : advance_road(d, env, e, tick, tidx)) + rec_ovf_sp(d.rec[env * d.R + e].y);
+        }
       }
       // rewards[:] = 0 (:233) then -= OVERFLOW_PENALTY per dropped car (:110): exact in fp32
       float rw = (d.accum_rewards && tidx > 0) ? d.rewards[(size_t)env * d.I + s] : 0.0f;
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void k_advance(const Dev d, const int tidx) {
        gid += (long)gridDim.x * blockDim.x) {
     const int env = (int)(gid / per_env);
     if (gid == 0) *d.tickA = tick + 1;
-    advance_item<TL, HET, GREEDY>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
+    advance_item<TL, HET, GREEDY, true, TL>(d, env, (int)(gid - (long)env * per_env), tick, tidx);
   }
 }
 

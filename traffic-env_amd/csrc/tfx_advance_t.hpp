@@ -26,13 +26,56 @@ __device__ __forceinline__ void compact_head_rows(const Dev &d, int id, int hb, 
   d.hb[id] = 0;
 }
 
+// Everything advance_road_t reads before it stores anything: the road's own words, its predecessor's pop count and - if
+// there are any - the (at most TFX_KP) cars the predecessor left in its outbox column.  Split from the stores so that a
+// lane that settles several roads (k_advance: the four approaches of an intersection) can issue all their loads first:
+// taken road by road, every road's chain of dependent loads (own words -> pred -> its record -> outbox) waited for the
+// stores of the road before it - twelve levels per lane where three do (cfg4 at one env: k_advance 7.3 us per tick).
+struct RoadAdvIn {
+  int ld, lc, hb, k_p;
+  int4 rc;
+  float2 car[KP];
+  float cw[KP];
+};
+
 template <bool HET = false, bool WP = true>
-__device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
+__device__ __forceinline__ RoadAdvIn advance_road_t_load(const Dev &d, int env, int e) {
+  RoadAdvIn in;
+  const int id = env * d.R + e;
+  in.ld = d.leading[id];
+  in.lc = d.lastcar[id];
+  in.rc = d.rec[id];
+  in.hb = 0;
+  in.k_p = 0;
+#pragma unroll
+  for (int j = 0; j < KP; ++j) {
+    in.car[j] = make_float2(0.0f, 0.0f);
+    in.cw[j] = 0.0f;
+  }
+  const int p = d.pred[e];
+  if (p >= 0) {
+    in.k_p = rec_kpop(d.rec[env * d.R + p].x);
+    if (in.k_p > 0) {
+      in.hb = d.hb[id];
+      const size_t pcol = ocol_of(d, env, p);
+#pragma unroll
+      for (int j = 0; j < KP; ++j)  // (k_p <= TFX_KP here: an env with a longer pop run takes the serial form)
+        if (j < in.k_p) {
+          in.car[j] = d.outb[pcol + (size_t)j * 64];
+          if (d.w) in.cw[j] = d.outw[pcol + (size_t)j * 64];
+        }
+    }
+  }
+  return in;
+}
+
+template <bool HET = false, bool WP = true>
+__device__ __forceinline__ int advance_road_t_apply(const Dev &d, int env, int e, const RoadAdvIn &in) {
   const int C = d.C;
   const int id = env * d.R + e;
-  const int ld = d.leading[id];
-  int lc = d.lastcar[id];
-  const int4 rc = d.rec[id];
+  const int ld = in.ld;
+  int lc = in.lc;
+  const int4 rc = in.rc;
   const int k_e = rec_kpop(rc.x);
   float tail_x = __int_as_float(rc.z);
   const int ld_post = ring_adv(ld, k_e, C);
@@ -40,21 +83,21 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
   int ta = rec_taila(rc.w);      // heterogeneous cars: table row of the tail (whose length and gap a push queues behind)
 
   int ovf = 0;
-  const int p = d.pred[e];
-  if (p >= 0) {
-    const int idp = env * d.R + p;
-    const int k_p = rec_kpop(d.rec[idp].x);
-    if (k_p > 0) {
-      int hb = d.hb[id];
-      if (hb > 0 && hb + m + k_p > d.trows) {
-        compact_head_rows<WP>(d, id, hb, m);
-        hb = 0;
-      }
-      m += hb;  // first free row
-      const int ld_seen = (p < e) ? ld : ld_post;
-      const size_t pcol = ocol_of(d, env, p), ecol = tcol(d, env, e);
-      for (int j = 0; j < k_p; ++j) {  // (k_p <= TFX_KP here: an env with a longer pop run takes the serial form)
-        const float2 car = d.outb[pcol + (size_t)j * 64];
+  const int k_p = in.k_p;
+  if (k_p > 0) {
+    const int p = d.pred[e];
+    int hb = in.hb;
+    if (hb > 0 && hb + m + k_p > d.trows) {
+      compact_head_rows<WP>(d, id, hb, m);
+      hb = 0;
+    }
+    m += hb;  // first free row
+    const int ld_seen = (p < e) ? ld : ld_post;
+    const size_t ecol = tcol(d, env, e);
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+      if (j < k_p) {
+        const float2 car = in.car[j];
         const float xc = car.x - d.length;  // state[e,xi,newlead] -= length (:130)
         const int pos = wrap1(lc + 1, C);
         const float tl = HET ? d.arch_tab[ta * ARCH_W + AR_L] : d.car_l, ts0 = HET ? d.arch_tab[ta * ARCH_W + AR_S0] : d.car_s0;
@@ -63,7 +106,7 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
           const float xv = (start < xc) ? start : xc;
           d.xv[ecol + (size_t)m * 64] = make_float2(xv, car.y);
           if (d.w) {
-            const float cw = d.outw[pcol + (size_t)j * 64];
+            const float cw = in.cw[j];
             d.w[ecol + (size_t)m * 64] = cw;
             if (HET) ta = side_arch(cw);
           }
@@ -74,13 +117,19 @@ __device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
           ++ovf;
         }
       }
-      d.lastcar[id] = lc;
     }
+    d.lastcar[id] = lc;
   }
   if (k_e > 0) d.leading[id] = ld_post;
   d.tailx[id] = tail_x;
   if (HET) d.taila[id] = ta;
   return ovf;
+}
+
+template <bool HET = false, bool WP = true>
+__device__ __forceinline__ int advance_road_t(const Dev &d, int env, int e) {
+  const RoadAdvIn in = advance_road_t_load<HET, WP>(d, env, e);
+  return advance_road_t_apply<HET, WP>(d, env, e, in);
 }
 
 // Literal single-thread advance for one env on the transposed layout (an env in which some car

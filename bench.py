@@ -152,9 +152,9 @@ def roofline(a, c, eng, E, prof, prof_updates, chunk, dt, updates):
     rest_ms = prof["advance_ms"] / max(1, K)
     kernel = eng.step_kernel()
     if 2 * (eng.pair_ticks()) >= K and kernel.startswith("k_move_tt"):
-        kernel = "k_move_tt"
+        kernel = "k_move_tts" if kernel == "k_move_tts" else "k_move_tt"      # (tts: two wavefronts per tile, mid-size launches)
     call = min(chunk, K)                                                # ticks per tfx_step call
-    tpl = (call if kernel == "k_res" else 2 if kernel == "k_move_tt" else 1)     # ticks per LAUNCH
+    tpl = (call if kernel == "k_res" else 2 if kernel in ("k_move_tt", "k_move_tts") else 1)     # ticks per LAUNCH
     passes = 1                                                                  # trips of the cars through HBM per launch
     launch_ms = move_ms * tpl
     full = E == c["envs"]

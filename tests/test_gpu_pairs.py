@@ -18,21 +18,24 @@ torch = pytest.importorskip("torch")
 from gym_traffic import workload as wl  # noqa: E402
 
 
-_TAIL = ["2", "0"]
+_TAIL = ["2", "0", "0"]
 
 
-@pytest.fixture(params=["tail", "launches", "split"], autouse=True)
+@pytest.fixture(params=["tail", "launches", "split", "seg_tail", "seg_launches"], autouse=True)
 def pair_tail(request):
     """What follows a pass: k_tail - advance(t), the edge work of t+1 and advance(t+1) in one launch, a workgroup per
     env (csrc/tfx_tail.hpp, forced at test sizes) - or the three separate launches; "split": k_tail, and tfx_step runs
-    the env range as two halves on two streams (tfx_split_ticks)."""
-    _TAIL[:] = ["0" if request.param == "launches" else "2", "2" if request.param == "split" else "0"]
+    the env range as two halves on two streams (tfx_split_ticks).  "seg_*": the pass with every tile's walk split over
+    two wavefronts (k_move_tts, csrc/tfx_move_tts.hpp - what launches that cannot fill the chip take), forced wherever
+    that form exists (plain cars outside agent steps)."""
+    _TAIL[:] = ["0" if request.param.endswith("launches") else "2", "2" if request.param == "split" else "0",
+                "2" if request.param.startswith("seg") else "0"]
     yield request.param
-    _TAIL[:] = ["2", "0"]
+    _TAIL[:] = ["2", "0", "0"]
 
 
 def pairs_engine(E, **cfg):
-    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": _TAIL[0], "TFX_SPLIT": _TAIL[1]}, E, **cfg)
+    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": _TAIL[0], "TFX_SPLIT": _TAIL[1], "TFX_TT_SEG": _TAIL[2]}, E, **cfg)
     assert eng.pair_ticks() == 0
     return eng
 
@@ -91,7 +94,9 @@ def test_pairs_random_states_vs_oracle(m, n, C, length, validate, sorted_x):
             for k in range(E):
                 kk = min(int(nt[k]), eng.trip_cap)
                 assert np.array_equal(eng.trip_times[k, :kk].cpu().numpy(), orc.trip_times[k, :kk]), (trial, k)
-    assert eng.pair_ticks() == ran and eng.step_kernel() == "k_move_tt"
+    # (the last call had an even number of ticks: its last mover was a pass - in its two-wavefronts-per-tile form where
+    # that was asked for and exists: plain cars)
+    assert eng.pair_ticks() == ran and eng.step_kernel() == ("k_move_tts" if _TAIL[2] == "2" and not validate else "k_move_tt")
     assert eng.tail_ticks() == (ran if _TAIL[0] == "2" else 0)
     assert (eng.split_ticks() > 0) == (_TAIL[1] == "2")
 

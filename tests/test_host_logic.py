@@ -320,6 +320,7 @@ def test_pmc_summary_tells_the_move_kernels_apart():
     assert ps.short("void tfx::k_move_t<4, 3, false>(tfx::Dev, int)") == "k_move_t"
     assert ps.short("void tfx::k_tail<false>(tfx::Dev, int)") == "k_tail"
     assert ps.short("void tfx::k_move_ts<16, false>(tfx::Dev, int)") == "k_move_ts"
+    assert ps.short("void tfx::k_move_tts<false, false>(tfx::Dev, int)") == "k_move_tts"
     assert ps.short("void tfx::k_edge<false>(tfx::Dev, int)") == "k_edge"
     assert ps.short("void tfx::k_advance<true>(tfx::Dev, int)") == "k_advance"
     assert ps.short("void tfx::k_res<2, false>(tfx::Dev, tfx::ResArgs)") == "k_res"

@@ -24,7 +24,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MOVERS = ("k_res", "k_move_dma", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t", "k_move")
+MOVERS = ("k_res", "k_move_dma", "k_move_tts", "k_move_ts", "k_move_tt", "k_move_tt1", "k_move_t", "k_move")
 
 
 def _code_only(text):

@@ -8,7 +8,7 @@ O=gpurun_out/${1:?outdir}; RD=${2:-r04}; B=gpurun_out/${3:-$1}
 N="TFX_SPLIT=0 bench.py --config CFG --steps 50 --warmup 10 (after the workload's settle ticks) under rocprofv3 (separate FETCH_SIZE / WRITE_SIZE / SQ passes)"
 python3 tools/pmc_summary.py --round $RD --config cfg2 --kt $O/cfg2_kt --pmc $O/cfg2_fetch $O/cfg2_write $O/cfg2_sq --kernel k_move_tt \
   --ticks-per-launch 2 --read-bytes-expected 1.89e9 --note "${N/CFG/cfg2}; k_move_tt<true> = one two-tick pass of all 4096 envs"
-python3 tools/pmc_summary.py --round $RD --config cfg4 --kt $O/cfg4_kt --pmc $O/cfg4_fetch $O/cfg4_write $O/cfg4_sq --kernel k_move_tt \
+python3 tools/pmc_summary.py --round $RD --config cfg4 --kt $O/cfg4_kt --pmc $O/cfg4_fetch $O/cfg4_write $O/cfg4_sq --kernel k_move_tts \
   --ticks-per-launch 2 --note "${N/CFG/cfg4}"
 python3 tools/pmc_summary.py --round $RD --config cfg1 --kt $O/cfg1_kt --pmc $O/cfg1_fetch $O/cfg1_write $O/cfg1_sq --kernel k_res \
   --ticks-per-launch 50 --note "${N/CFG/cfg1}; one k_res launch = the 50 timed ticks"

@@ -48,6 +48,8 @@ struct tfx_handle_s {
   int grid_move = 0;
   int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
+  int grid_tts = 0;           // k_move_tts (two wavefronts per tile)
+  int tt_seg = 1;             // TFX_TT_SEG: 0 never, 1 launches that leave wave slots empty, 2 whenever the form exists
   int grid_adv = 0;
   int grid_tail = 0, grid_tail_half = 0;  // k_tail: workgroups of 256 lanes / of 128 (the halves of a split call)
   int tail_threads = 256, tail_threads_half = 128;

@@ -10,6 +10,7 @@
 #include "tfx_resident.hpp"
 #include "tfx_advance.hpp"
 #include "tfx_tail.hpp"
+#include "tfx_move_tts.hpp"
 
 namespace {
 
@@ -417,6 +418,11 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
     if (occ != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 6) per_cu = 6;
     resident = h->n_cu * per_cu;
+    if (TWO && !AGENT && h->grid_tts == 0) {  // (sized here: occupancy queries stay outside stream captures)
+      int pc2 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, k_move_tts<false, false>, 256, 0) != hipSuccess || pc2 < 1) pc2 = 3;
+      h->grid_tts = h->n_cu * pc2 * 2;  // (a second round of workgroups evens out the end of the launch)
+    }
   }
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
@@ -430,6 +436,25 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   static const bool want_stagger = !(getenv("TFX_STAGGER") && atoi(getenv("TFX_STAGGER")) == 0);
   const bool stagger = want_stagger && TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
+  // Launches that leave most wave slots empty with one wavefront per tile: the tiles' walks split over two wavefronts
+  // (tfx_move_tts.hpp; plain cars outside agent steps).  Measured, us per tick with / without: cfg4 closed loop x 4 envs
+  // (1040 tiles) 41.7 / 58.5, x 16 (4160) 55.3 / 63.9; cfg2 x 128 envs (4352) 35.1 / 38.1, x 256 (8704) 51.6 / 46.1 -
+  // up to 20 tiles per CU.  TFX_TT_SEG=0 never, 2 whenever the form exists.
+  if (TWO && !AGENT && !only_risky && !h->d.het && !h->d.w && h->tt_seg &&
+      (h->tt_seg == 2 || (h->split_half < 0 && (long)h->d.E * h->d.G <= (long)h->n_cu * 20))) {
+    long gs = h->grid_tts > 0 ? h->grid_tts : (long)h->n_cu * 12;
+    const long n_pairs = ((long)h->d.E * h->d.G + 1) / 2;
+    if (gs > n_pairs) gs = n_pairs;
+    const dim3 g2((unsigned)gs), b2(256);
+    if (crec && rsw) hipLaunchKernelGGL((k_move_tts<true, true>), g2, b2, 0, st, h->d, tidx);
+    else if (crec) hipLaunchKernelGGL((k_move_tts<true, false>), g2, b2, 0, st, h->d, tidx);
+    else hipLaunchKernelGGL((k_move_tts<false, false>), g2, b2, 0, st, h->d, tidx);
+    HIPCHK(hipGetLastError());
+    h->step_kernel = "k_move_tts";
+    if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));
+    if (stagger) h->split_first = false;
+    return TFX_OK;
+  }
   const dim3 g((unsigned)grid), b(256);
   if (TWO && crec && rsw && !AGENT && !h->d.het) {
     constexpr bool CR = TWO && !AGENT;

@@ -437,11 +437,13 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   const bool stagger = want_stagger && TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
   // Launches that leave most wave slots empty with one wavefront per tile: the tiles' walks split over two wavefronts
-  // (tfx_move_tts.hpp; plain cars outside agent steps).  Measured, us per tick with / without: cfg4 closed loop x 4 envs
-  // (1040 tiles) 41.7 / 58.5, x 16 (4160) 55.3 / 63.9; cfg2 x 128 envs (4352) 35.1 / 38.1, x 256 (8704) 51.6 / 46.1 -
-  // up to 20 tiles per CU.  TFX_TT_SEG=0 never, 2 whenever the form exists.
+  // (tfx_move_tts.hpp; plain cars outside agent steps).  Measured, us per tick with / without: cfg4 (128-car rings)
+  // closed loop x 4 envs (1040 tiles) 41.7 / 58.5, x 8 (2080) 47.6, x 16 (4160) 55.3 / 63.9; cfg2 (64-car rings) x 128
+  // envs (2176 tiles) 35.1 / 38.1, x 256 (4352) 51.6 / 46.1: long walks up to 20 tiles per CU, short ones up to 10.
+  // TFX_TT_SEG=0 never, 2 whenever the form exists.
   if (TWO && !AGENT && !only_risky && !h->d.het && !h->d.w && h->tt_seg &&
-      (h->tt_seg == 2 || (h->split_half < 0 && (long)h->d.E * h->d.G <= (long)h->n_cu * 20))) {
+      (h->tt_seg == 2 ||
+       (h->split_half < 0 && (long)h->d.E * h->d.G <= (long)h->n_cu * (h->d.C - 2 > 64 ? 20 : 10)))) {
     long gs = h->grid_tts > 0 ? h->grid_tts : (long)h->n_cu * 12;
     const long n_pairs = ((long)h->d.E * h->d.G + 1) / 2;
     if (gs > n_pairs) gs = n_pairs;

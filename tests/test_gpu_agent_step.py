@@ -13,16 +13,21 @@ from gym_traffic import workload as wl  # noqa: E402
 from gym_traffic.core import TfxEngine  # noqa: E402
 
 
-@pytest.fixture(params=["resident", "pertick", "pairs"], autouse=True)
+@pytest.fixture(params=["resident", "pertick", "pairs", "pairs_seg", "pairs_seg_launches"], autouse=True)
 def step_path(request, monkeypatch):
     """Both forms of the fused decision: every tick in one LDS-resident launch (k_res, 3 envs per
     workgroup) and the captured sequence of per-tick kernels."""
     monkeypatch.setenv("TFX_RESIDENT", "1" if request.param == "resident" else "0")
     monkeypatch.setenv("TFX_RES_EPB", "3")
     # "pairs": two ticks per pass over the cars (k_move_tt + k_edge, k_risk inside agent steps), forced at test sizes
-    monkeypatch.setenv("TFX_PAIRS", "2" if request.param == "pairs" else "0")
-    monkeypatch.setenv("TFX_TAIL", "2")        # (with the pairs: k_tail behind every pass, csrc/tfx_tail.hpp,
-    monkeypatch.setenv("TFX_SPLIT", "2")       #  and the env range in two halves on two streams)
+    monkeypatch.setenv("TFX_PAIRS", "2" if request.param.startswith("pairs") else "0")
+    # (with the pairs: k_tail behind every pass, csrc/tfx_tail.hpp - "pairs_seg_launches": the separate launches, where
+    # the envs k_risk sorts out take the one-tick form inside the pass -, and the env range in two halves on two streams)
+    monkeypatch.setenv("TFX_TAIL", "0" if request.param == "pairs_seg_launches" else "2")
+    monkeypatch.setenv("TFX_SPLIT", "2")
+    # "pairs_seg*": the pass with every tile's walk split over two / four wavefronts (k_move_tts, csrc/tfx_move_tts.hpp)
+    monkeypatch.setenv("TFX_TT_SEG", "2" if request.param.startswith("pairs_seg") else "0")
+    monkeypatch.setenv("TFX_TT_SEGS", "4" if request.param == "pairs_seg_launches" else "2")
     yield request.param
 
 

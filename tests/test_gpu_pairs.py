@@ -18,24 +18,25 @@ torch = pytest.importorskip("torch")
 from gym_traffic import workload as wl  # noqa: E402
 
 
-_TAIL = ["2", "0", "0"]
+_TAIL = ["2", "0", "0", "0"]
 
 
-@pytest.fixture(params=["tail", "launches", "split", "seg_tail", "seg_launches"], autouse=True)
+@pytest.fixture(params=["tail", "launches", "split", "seg_tail", "seg_launches", "seg4_tail", "seg8_launches"], autouse=True)
 def pair_tail(request):
     """What follows a pass: k_tail - advance(t), the edge work of t+1 and advance(t+1) in one launch, a workgroup per
     env (csrc/tfx_tail.hpp, forced at test sizes) - or the three separate launches; "split": k_tail, and tfx_step runs
     the env range as two halves on two streams (tfx_split_ticks).  "seg_*": the pass with every tile's walk split over
-    two wavefronts (k_move_tts, csrc/tfx_move_tts.hpp - what launches that cannot fill the chip take), forced wherever
-    that form exists (plain cars outside agent steps)."""
+    two, four or eight wavefronts (k_move_tts, csrc/tfx_move_tts.hpp - what launches that cannot fill the chip take),
+    forced wherever that form exists (plain cars outside agent steps)."""
     _TAIL[:] = ["0" if request.param.endswith("launches") else "2", "2" if request.param == "split" else "0",
-                "2" if request.param.startswith("seg") else "0"]
+                "2" if request.param.startswith("seg") else "0",
+                "4" if request.param.startswith("seg4") else ("8" if request.param.startswith("seg8") else "2")]
     yield request.param
-    _TAIL[:] = ["2", "0", "0"]
+    _TAIL[:] = ["2", "0", "0", "0"]
 
 
 def pairs_engine(E, **cfg):
-    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": _TAIL[0], "TFX_SPLIT": _TAIL[1], "TFX_TT_SEG": _TAIL[2]}, E, **cfg)
+    eng = engine_with({"TFX_RESIDENT": "0", "TFX_PAIRS": "2", "TFX_TAIL": _TAIL[0], "TFX_SPLIT": _TAIL[1], "TFX_TT_SEG": _TAIL[2], "TFX_TT_SEGS": _TAIL[3]}, E, **cfg)
     assert eng.pair_ticks() == 0
     return eng
 

@@ -26,6 +26,8 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))     # two-tick passes + k_risk forced at any size | never
     os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2])))         # (plain step() calls between decisions: k_tail, split)
     os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))
+    os.environ["TFX_TT_SEG"] = str(int(rng.choice([0, 2])))        # the pass with every tile's walk split over wavefronts
+    os.environ["TFX_TT_SEGS"] = str(int(rng.choice([2, 4, 8])))
     val = bool(rng.randint(3) == 0)                               # validate mode: spawn ticks travel, trip times are logged
     # heterogeneous cars (one case in four on the transposed layout): a random table, the run starts from a random
     # ring state of mixed rows (arrivals are of row 0)

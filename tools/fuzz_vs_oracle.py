@@ -29,7 +29,7 @@ def run(seed, secs=420.0, state_file=None):
     if state_file:
         rng.set_state(pickle.load(open(state_file, "rb")))
     LIMIT = float(secs)
-    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS", "TFX_TAIL", "TFX_SPLIT")}
+    keep = {k: os.environ.get(k) for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS", "TFX_TAIL", "TFX_SPLIT", "TFX_TT_SEG", "TFX_TT_SEGS")}
     try:
         return _run(rng, seed, LIMIT)
     finally:
@@ -62,6 +62,8 @@ def _run(rng, seed, LIMIT):
         os.environ["TFX_PAIRS"] = str(int(rng.choice([0, 2, 2])))    # two-tick passes (k_move_tt + k_edge) forced at any size | never
         os.environ["TFX_TAIL"] = str(int(rng.choice([0, 2, 2])))     # ... finished by k_tail | by three launches
         os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))       # ... the env range in two halves on two streams
+        os.environ["TFX_TT_SEG"] = str(int(rng.choice([0, 2])))       # ... every tile's walk split over 2 / 4 / 8 wavefronts
+        os.environ["TFX_TT_SEGS"] = str(int(rng.choice([2, 4, 8])))
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
         planes = 3 if (val or layout == "ring") else 2
         # heterogeneous cars (one case in five on the transposed layout): a random table of 1..4 rows, exponents 1..8

@@ -48,7 +48,7 @@ struct tfx_handle_s {
   int grid_move = 0;
   int grid_tt[4] = {0, 0, 0, 0};  // k_move_tt<false>, <true>, <false, agent>, <true, agent>
   int grid_edge = 0;
-  int grid_tts = 0;           // k_move_tts (two wavefronts per tile)
+  int tt_segs = 0;            // TFX_TT_SEGS: 2 / 4 / 8 forces k_move_tts's wavefronts per tile (0: by launch size)
   int tt_seg = 1;             // TFX_TT_SEG: 0 never, 1 launches that leave wave slots empty, 2 whenever the form exists
   int grid_adv = 0;
   int grid_tail = 0, grid_tail_half = 0;  // k_tail: workgroups of 256 lanes / of 128 (the halves of a split call)

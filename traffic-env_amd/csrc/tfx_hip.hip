@@ -219,6 +219,7 @@ int tfx_create(const tfx_config *cfg, tfx_handle *out) {
   if (const char *tv = getenv("TFX_TAIL")) h->tail = atoi(tv);
   if (const char *sv = getenv("TFX_SPLIT")) h->split = atoi(sv);
   if (const char *gv = getenv("TFX_TT_SEG")) h->tt_seg = atoi(gv);
+  if (const char *gv = getenv("TFX_TT_SEGS")) h->tt_segs = atoi(gv);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

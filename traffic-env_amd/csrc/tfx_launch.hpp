@@ -378,8 +378,10 @@ bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
+  // (long rings - cfg4 - from two tiles per CU on: with their walks split over eight wavefronts, k_move_tts, the pairs
+  // overtake k_move_ts there: cfg4 closed loop x 2 envs 27.2 against 37.0 us per tick, x 3 30.4 against 41.4)
   const long tiles = (long)d.E * d.G;
-  return h->pairs == 2 || tiles >= (long)h->n_cu * 4;
+  return h->pairs == 2 || tiles >= (long)h->n_cu * ((d.C - 2 > 64 && !d.w && !h->het) ? 2 : 4);
 }
 
 int edge_grid(tfx_handle h) {
@@ -393,6 +395,25 @@ int edge_grid(tfx_handle h) {
     h->grid_edge = (int)(g < 1 ? 1 : g);
   }
   return h->grid_edge;
+}
+
+// Wavefronts per tile of a two-tick pass (0: one, k_move_tt).  Measured (us per tick; S = 0 / 2 / 4 / 8):
+//   cfg2 (47-row tiles, every road alike) x 64 envs (1088 tiles) 32.3 / 29.1 / 27.1 / 30.9; x 128 (2176) 38.1 / 35.1 /
+//   36.7 / 45.8; x 256 (4352) 46.0 / 51.8 / 55.4 / 74.3; x 512 72.2 / 79.7 / 89.8 / 134.8
+//   cfg4 (128-car rings) closed loop - a few long tiles among short ones - x 1 env (260 tiles; k_move_ts: 26.6) - / - /
+//   27.6 / 24.6; x 2 (37.0) - / - / 29.3 / 27.2; x 3 (41.4) - / - / 30.7 / 30.4; x 4 58.5 / 41.8 / 31.7 / 33.4; x 8 - /
+//   47.9 / 39.6 / 44.7; x 16 63.9 / 55.3 / 52.8 / 65.9; prefilled x 16 (every road full) 74.1 / 73.6 / 75.5 / 90.4
+//   fused 10-tick agent decisions, cfg4 prefilled, us, with / without: x 2 envs 325 / 725 (tick by tick: 378), x 3 343 / 721,
+//   x 4 423 / 738, x 8 582 / 626, x 16 (four segments) 871 / 825
+// Rule: the most segments that keep the launch within the chip's wave slots (6 per SIMD); long rings, whose launch is
+// as long as its longest tile's walk, take four up to 10 tiles per CU and two up to 20 even beyond that.
+int tt_segments(const tfx_handle_s *h) {
+  const long tiles = (long)h->d.E * h->d.G, slots = (long)h->n_cu * 24;
+  const bool long_rings = h->d.C - 2 > 64;
+  if (tiles * 8 <= slots) return 8;
+  if (tiles * 4 <= slots || (long_rings && tiles <= (long)h->n_cu * 10)) return 4;
+  if (tiles * 2 <= slots || (long_rings && tiles <= (long)h->n_cu * 20)) return 2;
+  return 0;
 }
 
 // AGENT: inside an agent step; only_risky: the second tick of the envs k_risk sorted out of a pair
@@ -418,11 +439,6 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
     if (occ != hipSuccess || per_cu < 1) per_cu = 4;
     if (per_cu > 6) per_cu = 6;
     resident = h->n_cu * per_cu;
-    if (TWO && !AGENT && h->grid_tts == 0) {  // (sized here: occupancy queries stay outside stream captures)
-      int pc2 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc2, k_move_tts<false, false>, 256, 0) != hipSuccess || pc2 < 1) pc2 = 3;
-      h->grid_tts = h->n_cu * pc2 * 2;  // (a second round of workgroups evens out the end of the launch)
-    }
   }
   h->step_kernel = "k_move_tt";
   if (h->size_only) return TFX_OK;
@@ -436,21 +452,31 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   static const bool want_stagger = !(getenv("TFX_STAGGER") && atoi(getenv("TFX_STAGGER")) == 0);
   const bool stagger = want_stagger && TWO && h->split_first && h->split_half >= 0;
   if (stagger && h->split_half == 1) HIPCHK(hipStreamWaitEvent(st, h->split_stagger, 0));
-  // Launches that leave most wave slots empty with one wavefront per tile: the tiles' walks split over two wavefronts
-  // (tfx_move_tts.hpp; plain cars outside agent steps).  Measured, us per tick with / without: cfg4 (128-car rings)
-  // closed loop x 4 envs (1040 tiles) 41.7 / 58.5, x 8 (2080) 47.6, x 16 (4160) 55.3 / 63.9; cfg2 (64-car rings) x 128
-  // envs (2176 tiles) 35.1 / 38.1, x 256 (4352) 51.6 / 46.1: long walks up to 20 tiles per CU, short ones up to 10.
-  // TFX_TT_SEG=0 never, 2 whenever the form exists.
-  if (TWO && !AGENT && !only_risky && !h->d.het && !h->d.w && h->tt_seg &&
-      (h->tt_seg == 2 ||
-       (h->split_half < 0 && (long)h->d.E * h->d.G <= (long)h->n_cu * (h->d.C - 2 > 64 ? 20 : 10)))) {
-    long gs = h->grid_tts > 0 ? h->grid_tts : (long)h->n_cu * 12;
-    const long n_pairs = ((long)h->d.E * h->d.G + 1) / 2;
-    if (gs > n_pairs) gs = n_pairs;
-    const dim3 g2((unsigned)gs), b2(256);
-    if (crec && rsw) hipLaunchKernelGGL((k_move_tts<true, true>), g2, b2, 0, st, h->d, tidx);
-    else if (crec) hipLaunchKernelGGL((k_move_tts<true, false>), g2, b2, 0, st, h->d, tidx);
-    else hipLaunchKernelGGL((k_move_tts<false, false>), g2, b2, 0, st, h->d, tidx);
+  // Launches that leave most wave slots empty with one wavefront per tile: the tiles' walks split over 2, 4 or 8
+  // wavefronts (tfx_move_tts.hpp, tt_segments; plain cars).  TFX_TT_SEG=0 never, 2 whenever the form
+  // exists; TFX_TT_SEGS = 2 / 4 / 8 forces the number.
+  if (TWO && !only_risky && !h->d.het && !h->d.w && h->tt_seg &&
+      (h->tt_seg == 2 || (h->split_half < 0 && tt_segments(h) > 0))) {
+    const long tiles_all = (long)h->d.E * h->d.G;
+    int S = tt_segments(h);
+    if (S == 0) S = 2;  // (forced: TFX_TT_SEG=2)
+    if (h->tt_segs == 2 || h->tt_segs == 4 || h->tt_segs == 8) S = h->tt_segs;
+    const long groups = S == 2 ? (tiles_all + 1) / 2 : tiles_all;
+    long gs = (long)h->n_cu * 16;  // (workgroups stride over the tiles)
+    if (gs > groups) gs = groups;
+    const dim3 g2((unsigned)gs), b2(S == 2 ? 256 : 64 * S);
+#define TFX_TTS_LAUNCH(SEGS)                                                                                   \
+    do {                                                                                                       \
+      if (AGENT && crec) hipLaunchKernelGGL((k_move_tts<AGENT, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);          \
+      else if (AGENT) hipLaunchKernelGGL((k_move_tts<AGENT, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);           \
+      else if (crec && rsw) hipLaunchKernelGGL((k_move_tts<false, true, true, SEGS>), g2, b2, 0, st, h->d, tidx);       \
+      else if (crec) hipLaunchKernelGGL((k_move_tts<false, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);             \
+      else hipLaunchKernelGGL((k_move_tts<false, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);                      \
+    } while (0)
+    if (S == 8) TFX_TTS_LAUNCH(8);
+    else if (S == 4) TFX_TTS_LAUNCH(4);
+    else TFX_TTS_LAUNCH(2);
+#undef TFX_TTS_LAUNCH
     HIPCHK(hipGetLastError());
     h->step_kernel = "k_move_tts";
     if (stagger && h->split_half == 0) HIPCHK(hipEventRecord(h->split_stagger, st));

@@ -15,8 +15,8 @@
 // held in registers (at most TFX_KP + 3) until a workgroup barrier behind both walks.  Before the walks a barrier
 // separates every read of the road's words and of B's start rows from the first store.
 // Counts, pops, tail and record meet in LDS; segment A's lanes write the road's outputs exactly as move_tt_tile does.
-// Plain cars outside agent steps (the forms mid-size tfx_step calls take); bit-identical to k_move_tt - every parity
-// test of the pairs runs through this kernel as well (TFX_TT_SEG=2).
+// Plain cars (tfx_step calls and agent steps); bit-identical to k_move_tt - every parity test of the pairs and of the
+// agent steps' pairs runs through this kernel as well (TFX_TT_SEG=2).
 #pragma once
 #include "tfx_move_tt.hpp"
 
@@ -24,15 +24,19 @@ namespace tfx {
 
 constexpr int TTS_HOLD = KP + 3;
 
-struct TtsShare {  // per tile of the workgroup: what segment B hands segment A
-  int n_wait[64], n_det[64], n_wait1[64], n_det1[64], kpop[64], flags[64];  // flags: 1 = B had cars, 2 = far
+struct TtsShare {  // per tile of the workgroup and per segment behind the first: what it hands segment A
+  int n_wait[64], n_det[64], n_wait1[64], n_det1[64], kpop[64], flags[64];  // flags: 1 = the segment had cars, 2 = far
   float y1x[64], y1v[64], tail_z[64];
 };
 
-// the two wavefronts (seg 0 = A, 1 = B) of one tile; `active`: the tile exists (both wavefronts reach every barrier anyway)
-template <bool CREC, bool RSW>
+// the S wavefronts (seg 0 = A, the others like B) of one tile; `active`: the tile exists (every wavefront reaches every
+// barrier anyway).  sh: S - 1 records, one per segment behind the first.
+// AGENT: inside an agent step - tiles of envs that stand still are skipped (`skip`: also the tiles k_tail takes through
+// both ticks itself), `two` = false: the tile of an env k_risk sorted out takes the one-tick form (as in move_tt_tile)
+template <bool AGENT, bool CREC, bool RSW, int S>
 __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, const bool active, const int lane, const int seg,
-                                                const int tick, const int tick_sp, const int tidx, TtsShare &sh) {
+                                                const int tick, const int tick_sp, const int tidx, TtsShare *sh,
+                                                const bool two = true, const bool skip = false) {
   constexpr int P = TT_P;
   const int C = d.C;
   const int env = active ? (int)(tile / d.G) : 0;
@@ -41,7 +45,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   const int e = valid ? e_slot : 0;
   const int id = env * d.R + e;
   const int hb0 = (valid && !RSW) ? d.hb[id] : 0;
-  const bool run = valid;
+  const bool run = valid && !skip && !(AGENT && env_frozen(d, env, tick));
   // (nobody stores a road word before the barrier below: the other segment may still have to read it)
   const RoadPrep p = prep_road<RSW>(d, id, env, e, tick, tick_sp, tidx, run, false);
   const int hb = run ? (RSW ? p.hb : hb0) : 0;
@@ -59,11 +63,13 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     kmax = o > kmax ? o : kmax;
   }
   kmax = __builtin_amdgcn_readfirstlane(kmax);
-  // the split point: A takes cars [0, h), B [h, ...); short tiles are not split
-  int h = ((kmax + 1) / 2 + P - 1) / P * P;
-  if (kmax < 4 * P) h = kmax;
-  const int k_lo = seg ? h : 0;
-  const int k_hi = seg ? kmax : (h < kmax ? h : kmax);
+  // the split: segment s takes cars [s * kseg, (s + 1) * kseg) - kseg a multiple of the prefetch depth, at least 2 P
+  // (a later segment needs the two cars in front of its first); short tiles leave the later segments idle
+  int kseg = ((kmax + S - 1) / S + P - 1) / P * P;
+  if (kseg < 2 * P) kseg = 2 * P;
+  const int h = seg * kseg;  // this segment's first car
+  const int k_lo = h < kmax ? h : kmax;
+  const int k_hi = (h + kseg < kmax) ? h + kseg : kmax;
 
   auto ld2 = [&](const float2 *ptr) {
     const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ptr));
@@ -90,7 +96,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   const int kq = (p.ld > p.lc) ? C - 1 - p.ld : 0x7fffffff;
   const bool mine = n_tot > k_lo;  // this lane's road has cars in this segment's range
 
-  if (seg == 1) {
+  if (seg > 0) {
     // ---- B's start: the pops of tick t in front of car h, then the old and new state of car h-1 -----------------
     for (int k = 0;; ++k) {
       const bool act = mine && open && k < h;
@@ -133,15 +139,15 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   }
 
   // where the next surviving car goes: one row further down per survivor (compacted by the pops in front of it)
-  float2 *wp = col + (size_t)(seg ? (kpop > KP ? h : h - kpop) : 0) * 64;
-  const float2 *const hold_below = col + (size_t)(h + hb) * 64;  // B: rows A may still be reading
+  float2 *wp = col + (size_t)(seg ? (kpop > KP ? k_lo : k_lo - kpop) : 0) * 64;
+  const float2 *const hold_below = col + (size_t)(k_lo + hb) * 64;  // B: rows the segment in front may still be reading
   // (B's stores go to consecutive rows, one per car from its first stored car on: the held ones are rows
   // hold_first, hold_first + 1, ...)
   float2 hold[TTS_HOLD];
   float2 *hold_first = nullptr;
   int n_hold = 0;
   auto st2 = [&](float2 *ptr, float a, float b) {
-    if (seg == 1 && ptr < hold_below && n_hold < TTS_HOLD) {
+    if (seg > 0 && ptr < hold_below && n_hold < TTS_HOLD) {
       // (unrolled select chain instead of an indexed store: the array stays in registers)
 #pragma unroll
       for (int q = 0; q < TTS_HOLD; ++q)
@@ -169,7 +175,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
       if (mode == 0) idm_step(d, x, v, xprev, vprev, llv, xn, vn);
       idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
     }
-    if (pend) {  // car k-1: the new head keeps its tick-t state (the edge work moves it), the others are a tick ahead
+    if (two && pend) {  // car k-1: the new head keeps its tick-t state (the edge work moves it), the others are a tick ahead
       st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
       wp += 64;
       if (pend_int) {
@@ -195,10 +201,13 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
       }
       far = far || ((xn - d.length) > d.length);
       ++kpop;
-    } else {
+    } else if (two) {
       pend = true;
       pend_int = !was_open;
       if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
+    } else {  // (the one-tick form: the survivor goes straight to its row)
+      st2(wp, xn, vn);
+      wp += 64;
     }
     const float wq = (k >= kq) ? xn : vn;
     n_wait += (wq < d.thresh) ? 1 : 0;
@@ -228,7 +237,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   // ---- the second tick of the segment's last car ------------------------------------------------------------------
   {
     const bool road_ends_here = n_tot > k_lo && n_tot <= k_hi;       // the road's last car is this segment's
-    const bool hand_over = seg == 0 && n_tot > k_hi && k_hi > 0;     // B continues the road behind A's last car
+    const bool hand_over = n_tot > k_hi && k_hi > k_lo;              // the next segment continues the road behind this one's last car
     if (__builtin_amdgcn_ballot_w64(pend && (road_ends_here || hand_over)) != 0ull) {
       if (pend && road_ends_here) step(n_tot, 0.0f, 0.0f, 1);
       else if (pend && hand_over) step(k_hi, 0.0f, 0.0f, 2);
@@ -236,19 +245,20 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   }
 
   // ---- the segments meet ------------------------------------------------------------------------------------------
-  if (seg == 1) {
-    sh.n_wait[lane] = n_wait;
-    sh.n_det[lane] = n_det;
-    sh.n_wait1[lane] = n_wait1;
-    sh.n_det1[lane] = n_det1;
-    sh.kpop[lane] = kpop;
-    sh.flags[lane] = (mine ? 1 : 0) | (far ? 2 : 0);
-    sh.y1x[lane] = y1x;
-    sh.y1v[lane] = y1v;
-    sh.tail_z[lane] = tail_z;
+  if (seg > 0) {
+    TtsShare &o = sh[seg - 1];
+    o.n_wait[lane] = n_wait;
+    o.n_det[lane] = n_det;
+    o.n_wait1[lane] = n_wait1;
+    o.n_det1[lane] = n_det1;
+    o.kpop[lane] = kpop;
+    o.flags[lane] = (mine ? 1 : 0) | (far ? 2 : 0);
+    o.y1x[lane] = y1x;
+    o.y1v[lane] = y1v;
+    o.tail_z[lane] = tail_z;
   }
-  __syncthreads();  // A has read every row it needed; B's counts are in LDS
-  if (seg == 1) {
+  __syncthreads();  // every segment has read every row it needed; the later segments' counts are in LDS
+  if (seg > 0) {
 #pragma unroll
     for (int q = 0; q < TTS_HOLD; ++q)
       if (q < n_hold) {
@@ -260,22 +270,35 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     return 0;
   }
   if (!run) return 0;
-  if (h < kmax) {
-    const int fl = sh.flags[lane];
-    n_wait += sh.n_wait[lane];
-    n_det += sh.n_det[lane];
-    n_wait1 += sh.n_wait1[lane];
-    n_det1 += sh.n_det1[lane];
-    far = far || (fl & 2);
-    if (fl & 1) {  // B saw the road's last cars: its pop count is the road's, the tail is its
-      kpop = sh.kpop[lane];
-      y1x = sh.y1x[lane];
-      y1v = sh.y1v[lane];
-      tail_z = sh.tail_z[lane];
+#pragma unroll
+  for (int q = 0; q < S - 1; ++q) {
+    if ((q + 1) * kseg < kmax) {  // (segment q + 1 had a range)
+      const TtsShare &o = sh[q];
+      const int fl = o.flags[lane];
+      n_wait += o.n_wait[lane];
+      n_det += o.n_det[lane];
+      n_wait1 += o.n_wait1[lane];
+      n_det1 += o.n_det1[lane];
+      far = far || (fl & 2);
+      if (fl & 1) {  // it saw cars of this road: the last such segment's pop count is the road's, the tail is its
+        kpop = o.kpop[lane];
+        y1x = o.y1x[lane];
+        y1v = o.y1v[lane];
+        tail_z = o.tail_z[lane];
+      }
     }
   }
-  // ---- phase W (move_tt_tile's, two ticks, plain cars) --------------------------------------------------------------
-  if (e < d.r && kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+  // ---- phase W (move_tt_tile's, plain cars) -------------------------------------------------------------------------
+  if (e < d.r) {
+    int *ob = d.obs + (size_t)env * d.obs_len;
+    if (n_tot > 0 && !two) {  // (a pair: edge_tile adds both ticks' waiting counts at once and stores `detected`)
+      d.waiting[(size_t)env * d.r + e] += n_wait;
+      ob[d.r + e] = n_det;
+    }
+    if (AGENT && !two) ob[e] = (tidx > 0) ? ob[e] + kpop : kpop;  // accumulates over the agent step
+    else if (!two) ob[e] = kpop;
+    if (kpop > 0) d.passed_dst[(size_t)env * d.I + e % d.I] = 1;
+  }
   const float tail_x = y1x;  // new x of the last car processed (0 if there was none)
   if (CREC) {
     d.crec[id] = make_int2(crec_pack<false>(kpop, n_tot, p.ld, p.lc, 0, kpop > KP, p.ovf_sp > 0), __float_as_int(tail_x));
@@ -283,28 +306,42 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   } else {
     d.rec[id] = make_int4(rec_pack(kpop, p.ld, C), rec_y(p.ovf_sp, kpop > KP), __float_as_int(tail_x), n_tot);
   }
-  d.rec2f[id] = make_float2(y1v, tail_z);
-  d.rec2c[id] = rec2c_pack(n_wait + n_wait1, n_det1, n_det, n_tot > 0);
+  if (two) {
+    d.rec2f[id] = make_float2(y1v, tail_z);
+    d.rec2c[id] = rec2c_pack(n_wait + n_wait1, n_det1, n_det, n_tot > 0);
+  }
   if (far || kpop > KP) d.env_flag[env] = tick + 1;
+  if (!two) d.leadx[id] = p.xL;  // (read by tfx_export_ring only: the second tick of a pair writes its own)
   return n_tot;
 }
 
-// a workgroup = two tiles x two segments
-template <bool CREC, bool RSW>
-__global__ __launch_bounds__(256) TT_ATTR(false) void k_move_tts(const Dev d, const int tidx) {
-  __shared__ TtsShare s_share[2];
+// a workgroup = TPW tiles x S segments (S = 2: two tiles; 4, 8: one)
+template <bool AGENT, bool CREC, bool RSW, int S>
+__global__ __launch_bounds__(S == 2 ? 256 : 64 * S) __attribute__((amdgpu_waves_per_eu(S == 2 ? TT_WAVES : 4, S == 2 ? TT_WAVES : 4)))
+void k_move_tts(const Dev d, const int tidx) {
+  static_assert(!RSW || (CREC && !AGENT), "road state words: between the pairs of a plain tfx_step call");
+  constexpr int TPW = S == 2 ? 2 : 1;
+  __shared__ TtsShare s_share[TPW][S - 1];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int seg = wv & 1, tl = wv >> 1;
+  const int seg = wv % S, tl = wv / S;
   const int tick = *d.tickA;
   const long tiles = (long)d.E * d.G;
-  const long n_pairs = (tiles + 1) / 2;
+  const long n_groups = (tiles + TPW - 1) / TPW;
   const int tick_sp = (d.spawn_mode == TFX_SPAWN_PERIODIC) ? tick % d.spawn_period : 0;
   unsigned long long my_updates = 0;
-  for (long pr = blockIdx.x; pr < n_pairs; pr += gridDim.x) {
-    const long tile = pr * 2 + tl;
-    my_updates += (unsigned long long)move_tt_tile_seg<CREC, RSW>(d, tile, tile < tiles, lane, seg, tick, tick_sp, tidx, s_share[tl]);
-    __syncthreads();  // (the LDS words are free for the next pair of tiles)
+  for (long pr = blockIdx.x; pr < n_groups; pr += gridDim.x) {
+    const long tile = pr * TPW + tl;
+    const bool active = tile < tiles;
+    // (k_move_tt's rules for the envs k_risk sorted out of this pair: behind k_tail their tiles are left alone, otherwise
+    // they take the one-tick form here and a restricted launch brings the second tick)
+    const int env = active ? (int)(tile / d.G) : 0;
+    const bool sorted_out = AGENT && active && risk_word(d, env, tidx) == tick + 1;
+    const bool two = CREC || !sorted_out;
+    if (AGENT && active && !two && lane == 0) risk_any_word(d, tidx) = tick + 1;
+    my_updates += (unsigned long long)move_tt_tile_seg<AGENT, CREC, RSW, S>(d, tile, active, lane, seg, tick, tick_sp, tidx, s_share[tl], two,
+                                                                          CREC && sorted_out);
+    __syncthreads();  // (the LDS words are free for the next tiles)
   }
   for (int off = 32; off > 0; off >>= 1) my_updates += __shfl_down(my_updates, off);
   if (lane == 0 && my_updates) veh_add(d.veh, my_updates);

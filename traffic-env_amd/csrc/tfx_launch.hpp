@@ -378,10 +378,11 @@ bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
-  // (long rings - cfg4 - from two tiles per CU on: with their walks split over eight wavefronts, k_move_tts, the pairs
-  // overtake k_move_ts there: cfg4 closed loop x 2 envs 27.2 against 37.0 us per tick, x 3 30.4 against 41.4)
+  // (long rings - cfg4 - from one tile per CU on: with their walks split over eight wavefronts, k_move_tts, the pairs
+  // overtake k_move_ts there: cfg4 closed loop x 1 env 24.6 against 26.7 us per tick, x 2 27.2 against 37.0, x 3 30.4
+  // against 41.4; prefilled x 1 env 18.6 against 23.5, a fused 10-tick decision 250 against 275 us)
   const long tiles = (long)d.E * d.G;
-  return h->pairs == 2 || tiles >= (long)h->n_cu * ((d.C - 2 > 64 && !d.w && !h->het) ? 2 : 4);
+  return h->pairs == 2 || tiles >= (long)h->n_cu * ((d.C - 2 > 64 && !d.w && !h->het) ? 1 : 4);
 }
 
 int edge_grid(tfx_handle h) {
@@ -473,7 +474,7 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
       else if (crec) hipLaunchKernelGGL((k_move_tts<false, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);             \
       else hipLaunchKernelGGL((k_move_tts<false, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);                      \
     } while (0)
-    if (S == 8) TFX_TTS_LAUNCH(8);
+    if (S == 8) TFX_TTS_LAUNCH(8);  // (sixteen: cfg4 x 1 env 25.1 against 24.6 us per tick, prefilled 21.4 against 18.5)
     else if (S == 4) TFX_TTS_LAUNCH(4);
     else TFX_TTS_LAUNCH(2);
 #undef TFX_TTS_LAUNCH

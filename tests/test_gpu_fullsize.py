@@ -80,7 +80,8 @@ def test_cfg2_full_size_properties(layout):
 def test_cfg2_full_size_two_tick_passes_vs_oracle():
     """The headline launch as the benchmark runs it: multi-tick calls, i.e. two-tick passes (k_move_tt + k_edge) over
     all 4096 envs.  Sampled envs equal the oracle bit for bit after calls of even and odd lengths; an env stepped
-    alone in a tiny batch (tick-by-tick kernels: too few tiles for the pairs) has the same trajectory."""
+    in a tiny batch (51 tiles: the pairs with every tile's walk split over eight wavefronts, k_move_tts, its odd ticks on
+    k_move_ts) has the same trajectory."""
     c = wl.CONFIGS["cfg2"]
     eng = wl.setup_engine("cfg2")
     C = eng.C
@@ -100,7 +101,8 @@ def test_cfg2_full_size_two_tick_passes_vs_oracle():
             assert np.array_equal(ld[k], orc.leading[0]) and np.array_equal(lc[k], orc.lastcar[0]), (t, k)
             assert np.array_equal(eng.obs[k].cpu().numpy(), orc.obs[0]), (t, k)
             assert np.array_equal(eng.waiting[k].cpu().numpy(), orc.waiting[0]), (t, k)
-    assert eng.pair_ticks() == 2 + 10 + 4 + 8 + 6 and small.pair_ticks() == 0
+    assert eng.pair_ticks() == 2 + 10 + 4 + 8 + 6 and small.pair_ticks() == eng.pair_ticks()
+    assert small.step_kernel() == "k_move_tts" and eng.step_kernel() == "k_move_tt"
     # ... behind every pass one k_tail launch, the batch in two halves on two streams (the defaults at this size)
     assert eng.tail_ticks() == eng.pair_ticks() and eng.split_ticks() == 2 + 10 + 5 + 8 + 6
     for (orc, ids), k in zip(orcs, sample):
@@ -373,15 +375,16 @@ def test_cfg1_full_batch_default_resident_packing_vs_oracle(monkeypatch):
     assert eng.step_kernel() == "k_res"
 
 
-@pytest.mark.parametrize("envs,expect", [(600, "split"), (300, "tail"), (96, "pairs"), (40, "graph")])
+@pytest.mark.parametrize("envs,expect", [(600, "split"), (300, "tail"), (96, "pairs"), (40, "graph"), (6, "small")])
 def test_default_heuristics_at_mid_batches_vs_oracle(envs, expect, monkeypatch):
     """The handle's OWN choices (no TFX_* switch set) between the headline batch and the tiny ones the rest of the suite
     forces paths on: 600 envs of the 16x16 grid take pairs + k_tail in two halves on two streams, 300 pairs + k_tail in
-    one range, 96 pairs with the three per-road launches, 40 the tick-by-tick kernels - the launch-bound ones replayed
-    as a HIP graph.  Calls of even and odd lengths and fused decisions in between; sampled envs equal the oracle bit for
+    one range, 96 pairs with the three per-road launches and every tile's walk split over two wavefronts (k_move_tts), 40
+    and 6 the same with four / eight wavefronts per tile - the launch-bound ones replayed as a HIP graph; a call's odd
+    last tick on k_move_ts where the launch is small enough for it.  Calls of even and odd lengths and fused decisions in between; sampled envs equal the oracle bit for
     bit, and the counters say the expected path ran."""
     for var in ("TFX_RES_EPB", "TFX_RES_LPR", "TFX_RESIDENT", "TFX_RES_MIN_TICKS", "TFX_PAIRS", "TFX_LAYOUT", "TFX_TAIL",
-                "TFX_SPLIT", "TFX_MOVE_VARIANT", "TFX_GRAPH", "TFX_KINDS", "TFX_FASTDIV"):
+                "TFX_SPLIT", "TFX_MOVE_VARIANT", "TFX_GRAPH", "TFX_KINDS", "TFX_FASTDIV", "TFX_TT_SEG"):
         monkeypatch.delenv(var, raising=False)
     c = wl.CONFIGS["cfg2"]
     eng = wl.setup_engine("cfg2", envs=envs)
@@ -411,10 +414,10 @@ def test_default_heuristics_at_mid_batches_vs_oracle(envs, expect, monkeypatch):
         assert eng.pair_ticks() == pairs and eng.tail_ticks() == pairs and eng.split_ticks() == 2 + 7 + 10 + 6 + 5
     elif expect == "tail":
         assert eng.pair_ticks() == pairs and eng.tail_ticks() == pairs and eng.split_ticks() == 0
-    elif expect == "pairs":
-        assert eng.pair_ticks() == pairs and eng.tail_ticks() == 0 and eng.split_ticks() == 0
     else:
-        assert eng.pair_ticks() == 0 and eng.step_kernel() in ("k_move_t", "k_move_ts")
+        assert eng.pair_ticks() == pairs and eng.tail_ticks() == 0 and eng.split_ticks() == 0
+        # (the last call's last tick was a single one: k_move_ts where the launch is small enough for it - 512 tiles)
+        assert eng.step_kernel() == ("k_move_ts" if envs * 17 <= 512 else "k_move_tt")
     # a fused decision on the same handle, against a second handle that takes it tick by tick
     ref = wl.setup_engine("cfg2", envs=envs)
     ref.step(31)

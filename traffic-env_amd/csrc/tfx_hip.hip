@@ -138,6 +138,7 @@ int step_graph(tfx_handle h, int n_ticks, hipStream_t st) {
     if (pairs_usable(h)) {
       (void)launch_move_tt<true>(h, 0, nullptr);
       (void)launch_move_tt<false>(h, 0, nullptr);
+      if (single_tick_ts(h)) (void)launch_move(h, 0, nullptr);  // (a call's odd last tick)
       if (tail_usable(h)) (void)launch_tail(h, 0, nullptr);
     } else {
       (void)launch_move(h, 0, nullptr);
@@ -658,7 +659,7 @@ int tfx_move_cars(tfx_handle h, void *stream) {
   if (int rc = check_handle(h, true)) return rc;
   if (int rc = launch_greedy(h, (hipStream_t)stream)) return rc;
   if (int rc = launch_inputs(h, (hipStream_t)stream)) return rc;
-  return pairs_usable(h) ? launch_move_tt<false>(h, 0, (hipStream_t)stream) : launch_move(h, 0, (hipStream_t)stream);
+  return (pairs_usable(h) && !single_tick_ts(h)) ? launch_move_tt<false>(h, 0, (hipStream_t)stream) : launch_move(h, 0, (hipStream_t)stream);
 }
 
 int tfx_advance_finished_cars(tfx_handle h, void *stream) {

@@ -378,11 +378,23 @@ bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
-  // (long rings - cfg4 - from one tile per CU on: with their walks split over eight wavefronts, k_move_tts, the pairs
-  // overtake k_move_ts there: cfg4 closed loop x 1 env 24.6 against 26.7 us per tick, x 2 27.2 against 37.0, x 3 30.4
-  // against 41.4; prefilled x 1 env 18.6 against 23.5, a fused 10-tick decision 250 against 275 us)
+  // Plain cars: always.  With the tiles' walks split over up to eight wavefronts (k_move_tts) the pairs beat the
+  // tick-by-tick kernels at every launch size - us per tick / us per fused 10-tick decision, pairs against tick by tick:
+  // cfg2 x 1 env (17 tiles) 14.3 / 207 against 18.5 / 215, x 8 16.1 / 226 against 20.3 / 236, x 32 21.6 / 281 against 34.9 /
+  // 374, x 48 21.9 / 288 against 52.2 / 535; cfg4 x 1 env (260 tiles) 18.5 / 245 against 23.5 / 275 (closed loop 24.6
+  // against 26.7), x 2 27.2 against 37.0, x 3 30.4 against 41.4.  (Single ticks of such handles: single_tick_ts.)
+  // The side-word forms (validate mode, heterogeneous cars) have no segmented pass: from four tiles per CU on.
   const long tiles = (long)d.E * d.G;
-  return h->pairs == 2 || tiles >= (long)h->n_cu * ((d.C - 2 > 64 && !d.w && !h->het) ? 1 : 4);
+  return h->pairs == 2 || (!d.w && !h->het) || tiles >= (long)h->n_cu * 4;
+}
+
+// A single tick of a handle that runs its calls as pairs: launches small enough for k_move_ts (several wavefronts per
+// tile, one tick; it reads past the rows a pair's second tick left empty like the one-tick form of k_move_tt does) take
+// it - the one-tick k_move_tt walks a tile with ONE wavefront (a 16x16 env's env.step(): 128-row columns).
+bool single_tick_ts(const tfx_handle_s *h) {
+  const long tiles = (long)h->d.E * h->d.G;
+  const long split_below = (h->d.C - 2 > 64) ? (long)h->n_cu * 9 / 2 : (long)h->n_cu * 2;
+  return !h->het && h->move_variant == 0 && h->d.layout == 1 && tiles <= split_below;
 }
 
 int edge_grid(tfx_handle h) {

@@ -49,6 +49,11 @@ __global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx)
     float2 *ocol = d.outb + ((size_t)tile * KP) * 64 + lane;
     float *wcol = W ? d.w + ((size_t)tile * d.trows) * 64 + lane : nullptr;
     float *owcol = W ? d.outw + ((size_t)tile * KP) * 64 + lane : nullptr;
+    // rows the second tick of a pair left empty at the top of the column (tfx_move_tt.hpp: a handle that runs its calls
+    // as pairs takes its single ticks here when the launch is small): read past them, write the column compacted
+    const int hb = (run && d.hb) ? d.hb[id] : 0;
+    const float2 *colr = col + (size_t)hb * 64;
+    const float *wcolr = W ? wcol + (size_t)hb * 64 : nullptr;
 
     int kmax = n_tot;
 #pragma unroll
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx)
 
     // old state of car k: a row of T, or a car spawned this tick queueing behind the tail (:97-114)
     auto old_car = [&](int k) {
-      if (k < n_old) return col[(size_t)k * 64];
+      if (k < n_old) return colr[(size_t)k * 64];
       return make_float2(spawned_x(d, p.xs0, k - n_old), d.car_v);
     };
     auto idm = [&](float x, float v, float xl, float vl, float ll, float &xn, float &vn) {
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx)
         const float2 c = old_car(k);
         cx[u] = c.x;
         cv[u] = c.y;
-        if (W) cw[u] = (k < n_old) ? wcol[(size_t)k * 64] : (float)tick;  // spawned this tick: w = tick
+        if (W) cw[u] = (k < n_old) ? wcolr[(size_t)k * 64] : (float)tick;  // spawned this tick: w = tick
       }
     }
     int n_wait = 0, n_det = 0;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(64 * S) void k_move_ts(const Dev d, const int tidx)
     }
     if (seg == S - 1) s_kpop[lane] = kpop;  // the last segment has seen every car in front of it
     __syncthreads();  // every segment has read the old rows it needs; the road's pop count is known
+    if (seg == 0 && hb) d.hb[id] = 0;
 
     {
       const bool unc = s_kpop[lane] > KP;  // > TFX_KP pops: every car back to its own row (see k_move_t)

@@ -148,7 +148,7 @@ int agent_sequence(tfx_handle h, int n_ticks, int remi, float *aobs, float *arew
       }
       for (; t < n_ticks && t < t0 + 2 && rc == TFX_OK; ++t) {
         rc = launch_inputs(h, st);
-        if (rc == TFX_OK) rc = tt ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
+        if (rc == TFX_OK) rc = (tt && !single_tick_ts(h)) ? launch_move_tt<false, true>(h, t, st) : launch_move(h, t, st);
         if (rc == TFX_OK) rc = launch_advance(h, t, st);
       }
     }
@@ -212,7 +212,7 @@ int step_range(tfx_handle h, int n_ticks, hipStream_t st, int t_lo = 0, int t_hi
     hipEvent_t *e = timed ? &h->ev[(size_t)h->ev_used * 3] : nullptr;
     if (int rc = launch_inputs(h, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[0], st));
-    if (int rc = tt ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
+    if (int rc = (tt && !single_tick_ts(h)) ? launch_move_tt<false>(h, t, st) : launch_move(h, t, st)) return rc;
     if (timed) HIPCHK(hipEventRecord(e[1], st));
     if (int rc = launch_advance(h, t, st)) return rc;
     if (timed) {

@@ -251,10 +251,11 @@ int tfx_launch_info(tfx_handle h, int32_t *grid, int32_t *block, int32_t *waves_
 int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
 /* Ticks of this handle that ran as two-tick passes since tfx_create (transposed layout: k_move_tt takes every
  * car but the head of each road through TWO ticks per trip through HBM, k_edge finishes the second tick for
- * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp).  tfx_step and tfx_agent_step use
- * them on their own for calls of two ticks or more whose launches fill the chip (from 4 tiles of 64 roads per
- * compute unit on), outside validate mode; results are bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0
- * turns them off, TFX_PAIRS=2 forces them at any size. */
+ * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp; launches that leave wave slots empty
+ * split every tile's walk over 2, 4 or 8 wavefronts: k_move_tts, csrc/tfx_move_tts.hpp).  tfx_step and tfx_agent_step
+ * use them on their own for calls of two ticks or more of every handle whose envs do not fit k_res - with the
+ * side-word plane (validate mode, heterogeneous cars) from 4 tiles of 64 roads per compute unit on; results are
+ * bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0 turns them off, TFX_PAIRS=2 forces them at any size. */
 int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
 /* ... of which the rest of the pair - advance_finished_cars of the first tick (traffic_env.py:117-135), the road
  * heads' second tick, advance_finished_cars of the second - ran as ONE launch with a workgroup per env (k_tail,
@@ -273,8 +274,8 @@ int tfx_slow_pairs(tfx_handle h, uint64_t *pairs, void *stream);
  * of pairs whose halves still fill the chip, never while tfx_profile is timing kernels.  TFX_SPLIT=0 turns it off,
  * TFX_SPLIT=2 forces it at any batch size; results are bit-identical (envs share nothing, traffic_env.py:361-382). */
 int tfx_split_ticks(tfx_handle h, int64_t *ticks);
-/* name of the kernel that moved the cars in the handle's last tick ("k_move_t", "k_move_ts", "k_res",
- * "k_move_dma", ...), for the roofline report; "" before the first step */
+/* name of the kernel that moved the cars in the handle's last tick ("k_move_tt", "k_move_tts", "k_move_t", "k_move_ts",
+ * "k_res", "k_move_dma", ...), for the roofline report; "" before the first step */
 const char *tfx_step_kernel(tfx_handle h);
 
 /* Error-path testing: the n-th kernel launch a later tfx_step / tfx_agent_step / tfx_move_cars /

@@ -28,6 +28,9 @@ while time.time() - t0 < float(os.environ.get("FUZZ_SECS", "300")):
     os.environ["TFX_SPLIT"] = str(int(rng.choice([0, 2])))
     os.environ["TFX_TT_SEG"] = str(int(rng.choice([0, 2])))        # the pass with every tile's walk split over wavefronts
     os.environ["TFX_TT_SEGS"] = str(int(rng.choice([2, 4, 8])))
+    if rng.randint(4) == 0:                                        # one case in four: the handle's own choices
+        for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_PAIRS", "TFX_TAIL", "TFX_SPLIT", "TFX_TT_SEG", "TFX_TT_SEGS"):
+            os.environ.pop(k, None)
     val = bool(rng.randint(3) == 0)                               # validate mode: spawn ticks travel, trip times are logged
     # heterogeneous cars (one case in four on the transposed layout): a random table, the run starts from a random
     # ring state of mixed rows (arrivals are of row 0)

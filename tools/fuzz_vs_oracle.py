@@ -65,6 +65,10 @@ def _run(rng, seed, LIMIT):
         os.environ["TFX_TT_SEG"] = str(int(rng.choice([0, 2])))       # ... every tile's walk split over 2 / 4 / 8 wavefronts
         os.environ["TFX_TT_SEGS"] = str(int(rng.choice([2, 4, 8])))
         if layout == "transposed" and mode == 2: os.environ["TFX_KINDS"] = "0"
+        if rng.randint(4) == 0:                # one case in four: the handle's own choices, no switch set
+            for k in ("TFX_RESIDENT", "TFX_RES_EPB", "TFX_RES_LPR", "TFX_KINDS", "TFX_MOVE_VARIANT", "TFX_PAIRS", "TFX_TAIL", "TFX_SPLIT",
+                      "TFX_TT_SEG", "TFX_TT_SEGS"):
+                os.environ.pop(k, None)
         planes = 3 if (val or layout == "ring") else 2
         # heterogeneous cars (one case in five on the transposed layout): a random table of 1..4 rows, exponents 1..8
         het = layout == "transposed" and rng.randint(5) == 0
@@ -142,7 +146,7 @@ def _run(rng, seed, LIMIT):
                                 if a.view(np.int32) != b.view(np.int32) and not (np.isnan(a) and np.isnan(b)):
                                     print("DIFF tick", t, "k", k, "env", kk, "road", e, "car", i, "of", cnt, nm, "gpu", a, "oracle", b,
                                           "pred", int(np.where(eng.nexts == e)[0][0]) if (eng.nexts == e).any() else -1, "next", int(eng.nexts[e]), flush=True)
-            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s tail=%s split=%s het=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ["TFX_PAIRS"], os.environ["TFX_TAIL"], os.environ["TFX_SPLIT"], het, t))
+            assert_same_state(eng, orc, "case %d (%dx%d C=%d E=%d %s val=%s mode=%d mv=%d pairs=%s tail=%s split=%s het=%s) tick %d" % (n, m, nn, C, E, layout, val, mode, mv, os.environ.get("TFX_PAIRS"), os.environ.get("TFX_TAIL"), os.environ.get("TFX_SPLIT"), het, t))
             if het:
                 a_dev = eng.arch.cpu().numpy(); ldh, lch = eng.leading.cpu().numpy(), eng.lastcar.cpu().numpy()
                 from oracle.oracle import live_mask

@@ -1,22 +1,24 @@
-// tfx_move_tts.hpp - k_move_tts: the two-tick pass (tfx_move_tt.hpp) with every tile's walk split over TWO wavefronts,
-// for launches that cannot fill the chip's wave slots with one wavefront per tile (cfg4 x 16 envs: 4160 tiles for 6144
-// slots; a 16x16 grid x 256 envs) - such a launch is as long as its longest tile's serial walk (cfg4: 128 rows x two
-// ticks), however many slots idle beside it.
+// tfx_move_tts.hpp - k_move_tts: the two-tick pass (tfx_move_tt.hpp) with every tile's walk split over S = 2, 4 or 8
+// wavefronts, for launches that cannot fill the chip's wave slots with one wavefront per tile (a few big envs: cfg4 x 16
+// envs is 4160 tiles for 6144 slots, one 16x16 env 17 tiles) - such a launch is as long as its longest tile's serial walk
+// (cfg4: 128 rows x two ticks), however many slots idle beside it.
 //
-// Segment A takes the cars 0 .. h-1 of every road of the tile, segment B the cars from h on (h: half the longest road,
-// a multiple of the prefetch depth; cars count old rows first, then this tick's arrivals).  What B needs to start in
-// the middle of a column is little, because the update is Jacobi:
+// Segment s takes the cars s kseg .. (s + 1) kseg - 1 of every road of the tile (kseg: the tile's longest road over S, a
+// multiple of the prefetch depth; cars count old rows first, then this tick's arrivals).  What a segment behind the first
+// ("B"; the first is "A") needs to start in the middle of a column is little, because the update is Jacobi:
 //   * the pops of tick t in front of it - the `while` of :123 is a prefix: B re-evaluates the head cars until one stays
 //     (usually the first), as k_move_ts's segments do;
-//   * the tick-t state of car h-1 (for car h's second tick): one IDM step on the old rows h-1 and h-2.
-// A takes car h-1 through its second tick itself (it holds y(h-1), y(h-2)), B stores z from car h on.
-// Stores: A's land in rows it has already read.  B's first few survivors belong in rows below h + hb - rows A may still
-// be reading (the column is compacted by the pops of tick t and by the empty rows hb the last pair left on top) - and are
-// held in registers (at most TFX_KP + 3) until a workgroup barrier behind both walks.  Before the walks a barrier
-// separates every read of the road's words and of B's start rows from the first store.
-// Counts, pops, tail and record meet in LDS; segment A's lanes write the road's outputs exactly as move_tt_tile does.
+//   * the tick-t state of the car in front of its first, h-1 (for car h's second tick): one IDM step on the old rows h-1
+//     and h-2.
+// Every segment takes its own last car through its second tick itself (it holds y(h-1), y(h-2)); the next one stores z
+// from its first car on.
+// Stores: a segment's land in rows it has already read - except B's first few survivors, which belong in rows below
+// h + hb: rows the segment in front may still be reading (the column is compacted by the pops of tick t and by the empty
+// rows hb the last pair left on top).  Those are held in registers (at most TFX_KP + 3) until a workgroup barrier behind
+// the walks.  Before the walks a barrier separates every read of the road's words and of the start rows from the first store.
+// Counts, pops, tail and record meet in LDS; the first segment's lanes write the road's outputs exactly as move_tt_tile does.
 // Plain cars (tfx_step calls and agent steps); bit-identical to k_move_tt - every parity test of the pairs and of the
-// agent steps' pairs runs through this kernel as well (TFX_TT_SEG=2).
+// agent steps' pairs runs through this kernel as well (TFX_TT_SEG=2, TFX_TT_SEGS=2/4/8), and the fuzzers draw it.
 #pragma once
 #include "tfx_move_tt.hpp"
 

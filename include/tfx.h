@@ -253,8 +253,8 @@ int tfx_fused_ticks(tfx_handle h, int64_t *ticks, int32_t *capable);
  * car but the head of each road through TWO ticks per trip through HBM, k_edge finishes the second tick for
  * the heads and the cars that joined a road in between - csrc/tfx_move_tt.hpp; launches that leave wave slots empty
  * split every tile's walk over 2, 4 or 8 wavefronts: k_move_tts, csrc/tfx_move_tts.hpp).  tfx_step and tfx_agent_step
- * use them on their own for calls of two ticks or more of every handle whose envs do not fit k_res - with the
- * side-word plane (validate mode, heterogeneous cars) from 4 tiles of 64 roads per compute unit on; results are
+ * use them on their own for calls of two ticks or more of every handle whose envs do not fit k_res - heterogeneous
+ * cars from 4 tiles of 64 roads per compute unit on; results are
  * bit-identical to the tick-by-tick kernels.  TFX_PAIRS=0 turns them off, TFX_PAIRS=2 forces them at any size. */
 int tfx_pair_ticks(tfx_handle h, int64_t *ticks);
 /* ... of which the rest of the pair - advance_finished_cars of the first tick (traffic_env.py:117-135), the road

@@ -27,7 +27,7 @@ def pair_tail(request):
     env (csrc/tfx_tail.hpp, forced at test sizes) - or the three separate launches; "split": k_tail, and tfx_step runs
     the env range as two halves on two streams (tfx_split_ticks).  "seg_*": the pass with every tile's walk split over
     two, four or eight wavefronts (k_move_tts, csrc/tfx_move_tts.hpp - what launches that cannot fill the chip take),
-    forced wherever that form exists (plain cars outside agent steps)."""
+    forced wherever that form exists (single-archetype cars, with or without the side-word plane)."""
     _TAIL[:] = ["0" if request.param.endswith("launches") else "2", "2" if request.param == "split" else "0",
                 "2" if request.param.startswith("seg") else "0",
                 "4" if request.param.startswith("seg4") else ("8" if request.param.startswith("seg8") else "2")]
@@ -95,9 +95,9 @@ def test_pairs_random_states_vs_oracle(m, n, C, length, validate, sorted_x):
             for k in range(E):
                 kk = min(int(nt[k]), eng.trip_cap)
                 assert np.array_equal(eng.trip_times[k, :kk].cpu().numpy(), orc.trip_times[k, :kk]), (trial, k)
-    # (the last call had an even number of ticks: its last mover was a pass - in its two-wavefronts-per-tile form where
-    # that was asked for and exists: plain cars)
-    assert eng.pair_ticks() == ran and eng.step_kernel() == ("k_move_tts" if _TAIL[2] == "2" and not validate else "k_move_tt")
+    # (the last call had an even number of ticks: its last mover was a pass - in its several-wavefronts-per-tile form
+    # where that was asked for)
+    assert eng.pair_ticks() == ran and eng.step_kernel() == ("k_move_tts" if _TAIL[2] == "2" else "k_move_tt")
     assert eng.tail_ticks() == (ran if _TAIL[0] == "2" else 0)
     assert (eng.split_ticks() > 0) == (_TAIL[1] == "2")
 

@@ -378,14 +378,14 @@ bool pairs_usable(tfx_handle h, int n_ticks = 2) {
   // measured, vehicle-updates/s with / without: cfg2 x 16 envs (272 tiles) 1.8e10 / 2.5e10 and cfg4 x 1 (260) 2.6e10 /
   // 3.8e10 - there four wavefronts per tile (k_move_ts) finish sooner; cfg4 x 4 (1040) 9.0e10 / 6.6e10, cfg2 x 64
   // (1088) 9.1e10 / 7.1e10, cfg2 x 128 1.6e11 / 1.3e11, cfg4 x 8 2.1e11 / 1.8e11, cfg2 x 256 2.5e11 / 2.1e11
-  // Plain cars: always.  With the tiles' walks split over up to eight wavefronts (k_move_tts) the pairs beat the
+  // Single-archetype cars (with or without the side-word plane): always.  With the tiles' walks split over up to eight wavefronts (k_move_tts) the pairs beat the
   // tick-by-tick kernels at every launch size - us per tick / us per fused 10-tick decision, pairs against tick by tick:
   // cfg2 x 1 env (17 tiles) 14.3 / 207 against 18.5 / 215, x 8 16.1 / 226 against 20.3 / 236, x 32 21.6 / 281 against 34.9 /
   // 374, x 48 21.9 / 288 against 52.2 / 535; cfg4 x 1 env (260 tiles) 18.5 / 245 against 23.5 / 275 (closed loop 24.6
   // against 26.7), x 2 27.2 against 37.0, x 3 30.4 against 41.4.  (Single ticks of such handles: single_tick_ts.)
-  // The side-word forms (validate mode, heterogeneous cars) have no segmented pass: from four tiles per CU on.
+  // Heterogeneous cars have no segmented pass: from four tiles per CU on.
   const long tiles = (long)d.E * d.G;
-  return h->pairs == 2 || (!d.w && !h->het) || tiles >= (long)h->n_cu * 4;
+  return h->pairs == 2 || !h->het || tiles >= (long)h->n_cu * 4;
 }
 
 // A single tick of a handle that runs its calls as pairs: launches small enough for k_move_ts (several wavefronts per
@@ -468,7 +468,7 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
   // Launches that leave most wave slots empty with one wavefront per tile: the tiles' walks split over 2, 4 or 8
   // wavefronts (tfx_move_tts.hpp, tt_segments; plain cars).  TFX_TT_SEG=0 never, 2 whenever the form
   // exists; TFX_TT_SEGS = 2 / 4 / 8 forces the number.
-  if (TWO && !only_risky && !h->d.het && !h->d.w && h->tt_seg &&
+  if (TWO && !only_risky && !h->d.het && h->tt_seg &&
       (h->tt_seg == 2 || (h->split_half < 0 && tt_segments(h) > 0))) {
     const long tiles_all = (long)h->d.E * h->d.G;
     int S = tt_segments(h);
@@ -480,11 +480,17 @@ int launch_move_tt(tfx_handle h, int tidx, hipStream_t st, int only_risky = 0, b
     const dim3 g2((unsigned)gs), b2(S == 2 ? 256 : 64 * S);
 #define TFX_TTS_LAUNCH(SEGS)                                                                                   \
     do {                                                                                                       \
-      if (AGENT && crec) hipLaunchKernelGGL((k_move_tts<AGENT, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);          \
-      else if (AGENT) hipLaunchKernelGGL((k_move_tts<AGENT, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);           \
-      else if (crec && rsw) hipLaunchKernelGGL((k_move_tts<false, true, true, SEGS>), g2, b2, 0, st, h->d, tidx);       \
-      else if (crec) hipLaunchKernelGGL((k_move_tts<false, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);             \
-      else hipLaunchKernelGGL((k_move_tts<false, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);                      \
+      if (h->d.w) {                                                                                                      \
+        if (AGENT && crec) hipLaunchKernelGGL((k_move_tts<AGENT, true, false, SEGS, true>), g2, b2, 0, st, h->d, tidx);   \
+        else if (AGENT) hipLaunchKernelGGL((k_move_tts<AGENT, false, false, SEGS, true>), g2, b2, 0, st, h->d, tidx);     \
+        else if (crec && rsw) hipLaunchKernelGGL((k_move_tts<false, true, true, SEGS, true>), g2, b2, 0, st, h->d, tidx); \
+        else if (crec) hipLaunchKernelGGL((k_move_tts<false, true, false, SEGS, true>), g2, b2, 0, st, h->d, tidx);       \
+        else hipLaunchKernelGGL((k_move_tts<false, false, false, SEGS, true>), g2, b2, 0, st, h->d, tidx);                \
+      } else if (AGENT && crec) hipLaunchKernelGGL((k_move_tts<AGENT, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);    \
+      else if (AGENT) hipLaunchKernelGGL((k_move_tts<AGENT, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);             \
+      else if (crec && rsw) hipLaunchKernelGGL((k_move_tts<false, true, true, SEGS>), g2, b2, 0, st, h->d, tidx);         \
+      else if (crec) hipLaunchKernelGGL((k_move_tts<false, true, false, SEGS>), g2, b2, 0, st, h->d, tidx);               \
+      else hipLaunchKernelGGL((k_move_tts<false, false, false, SEGS>), g2, b2, 0, st, h->d, tidx);                        \
     } while (0)
     if (S == 8) TFX_TTS_LAUNCH(8);  // (sixteen: cfg4 x 1 env 25.1 against 24.6 us per tick, prefilled 21.4 against 18.5)
     else if (S == 4) TFX_TTS_LAUNCH(4);

@@ -17,7 +17,7 @@
 // rows hb the last pair left on top).  Those are held in registers (at most TFX_KP + 3) until a workgroup barrier behind
 // the walks.  Before the walks a barrier separates every read of the road's words and of the start rows from the first store.
 // Counts, pops, tail and record meet in LDS; the first segment's lanes write the road's outputs exactly as move_tt_tile does.
-// Plain cars (tfx_step calls and agent steps); bit-identical to k_move_tt - every parity test of the pairs and of the
+// Single-archetype cars, with or without the side-word plane (tfx_step calls and agent steps); bit-identical to k_move_tt - every parity test of the pairs and of the
 // agent steps' pairs runs through this kernel as well (TFX_TT_SEG=2, TFX_TT_SEGS=2/4/8), and the fuzzers draw it.
 #pragma once
 #include "tfx_move_tt.hpp"
@@ -35,7 +35,8 @@ struct TtsShare {  // per tile of the workgroup and per segment behind the first
 // barrier anyway).  sh: S - 1 records, one per segment behind the first.
 // AGENT: inside an agent step - tiles of envs that stand still are skipped (`skip`: also the tiles k_tail takes through
 // both ticks itself), `two` = false: the tile of an env k_risk sorted out takes the one-tick form (as in move_tt_tile)
-template <bool AGENT, bool CREC, bool RSW, int S>
+// W: the spawn-tick plane travels with the cars (validate mode): a car's side word is stored wherever its (x, v) is
+template <bool AGENT, bool CREC, bool RSW, int S, bool W = false>
 __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, const bool active, const int lane, const int seg,
                                                 const int tick, const int tick_sp, const int tidx, TtsShare *sh,
                                                 const bool two = true, const bool skip = false) {
@@ -57,6 +58,9 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   float2 *col = d.xv + ((size_t)(active ? tile : 0) * d.trows) * 64 + lane;
   const float2 *colr = col + (size_t)hb * 64;
   float2 *ocol = d.outb + ((size_t)(active ? tile : 0) * KP) * 64 + lane;
+  float *wcol = W ? d.w + ((size_t)(active ? tile : 0) * d.trows) * 64 + lane : nullptr;  // side words: same rows as col
+  const float *wcolr = W ? wcol + (size_t)hb * 64 : nullptr;
+  float *owcol = W ? d.outw + ((size_t)(active ? tile : 0) * KP) * 64 + lane : nullptr;
 
   int kmax = n_tot;
 #pragma unroll
@@ -82,6 +86,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     if (k < n_old) return ld2(&colr[(size_t)k * 64]);
     return make_float2(spawned_x(d, p.xs0, k - n_old), d.car_v);
   };
+  auto old_w = [&](int k) { return (W && k < n_old) ? wcolr[(size_t)k * 64] : (float)tick; };  // spawned this tick: w = tick
   auto idm = [&](float x, float v, float xl, float vl, float ll, float &xn, float &vn) {
     const bool off_domain = __builtin_amdgcn_ballot_w64(!idm_fast_domain(v)) != 0ull;
     if (d.fastdiv && !off_domain) idm_step_fast(d, x, v, xl, vl, ll, xn, vn);
@@ -90,6 +95,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
 
   float xprev = p.xL, vprev = 0.0f, llv = 0.0f;  // OLD state of the car ahead (Jacobi); starts as the fake leader
   float y1x = 0.0f, y1v = 0.0f, y2x = 0.0f, y2v = 0.0f;  // NEW states of cars k-1 and k-2
+  float y1w = 0.0f;                                      // side word of car k-1
   int kpop = 0, n_wait = 0, n_det = 0, n_wait1 = 0, n_det1 = 0;
   bool open = true, far = false;
   bool pend = false, pend_int = false;
@@ -130,6 +136,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
         llv = d.car_l;
         y1x = xn;
         y1v = vn;
+        if (W) y1w = old_w(h - 1);
         if (!open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (set by the first survivor, which sits in A's range)
       }
     }
@@ -146,14 +153,19 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
   // (B's stores go to consecutive rows, one per car from its first stored car on: the held ones are rows
   // hold_first, hold_first + 1, ...)
   float2 hold[TTS_HOLD];
+  float hold_w[W ? TTS_HOLD : 1];
   float2 *hold_first = nullptr;
   int n_hold = 0;
-  auto st2 = [&](float2 *ptr, float a, float b) {
+  // (x, v) - and, W, the side word sw - of a car into row `ptr` of the column
+  auto st2 = [&](float2 *ptr, float a, float b, float sw) {
     if (seg > 0 && ptr < hold_below && n_hold < TTS_HOLD) {
       // (unrolled select chain instead of an indexed store: the array stays in registers)
 #pragma unroll
       for (int q = 0; q < TTS_HOLD; ++q)
-        if (q == n_hold) hold[q] = make_float2(a, b);
+        if (q == n_hold) {
+          hold[q] = make_float2(a, b);
+          if (W) hold_w[q] = sw;
+        }
       if (n_hold == 0) hold_first = ptr;
       ++n_hold;
       return;
@@ -162,11 +174,12 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     t.x = a;
     t.y = b;
     __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(ptr));
+    if (W) wcol[ptr - col] = sw;
   };
 
   // Car k through tick t, car k-1 through tick t+1 (move_tt_tile's step, plain cars, always two ticks).
   // mode 0: a car; 1: the road's last car's second tick only; 2: A's last car's second tick only (B continues the road)
-  auto step = [&](int k, float x, float v, int mode) {
+  auto step = [&](int k, float x, float v, float sw, int mode) {
     float xn = 0.0f, vn = 0.0f, zx = 0.0f, zv = 0.0f;
     const bool bad = (mode == 0 && !idm_fast_domain(v)) || !idm_fast_domain(y1v);
     const bool off_domain = __builtin_amdgcn_ballot_w64(bad) != 0ull;
@@ -178,7 +191,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
       idm_step(d, y1x, y1v, y2x, y2v, d.car_l, zx, zv);
     }
     if (two && pend) {  // car k-1: the new head keeps its tick-t state (the edge work moves it), the others are a tick ahead
-      st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v);
+      st2(wp, pend_int ? zx : y1x, pend_int ? zv : y1v, y1w);
       wp += 64;
       if (pend_int) {
         const float wq1 = (k - 1 >= kq1) ? zx : zv;
@@ -197,8 +210,9 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     if (pop) {
       if (kpop < KP) {
         ocol[(size_t)kpop * 64] = make_float2(xn, vn);
+        if (W) owcol[(size_t)kpop * 64] = sw;
       } else {  // third pop: no survivor has been written yet - from here on every car stays in its row
-        st2(&col[(size_t)k * 64], xn, vn);
+        st2(&col[(size_t)k * 64], xn, vn, sw);
         wp = col + (size_t)(k + 1) * 64;
       }
       far = far || ((xn - d.length) > d.length);
@@ -208,7 +222,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
       pend_int = !was_open;
       if (was_open) kq1 = C - 1 - ring_adv(p.ld, kpop, C) + kpop;  // (kpop is final: this is the first survivor)
     } else {  // (the one-tick form: the survivor goes straight to its row)
-      st2(wp, xn, vn);
+      st2(wp, xn, vn, sw);
       wp += 64;
     }
     const float wq = (k >= kq) ? xn : vn;
@@ -218,21 +232,31 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     y2v = y1v;
     y1x = xn;
     y1v = vn;
+    if (W) y1w = sw;
   };
 
   // ---- this segment's cars in memory: rows k_lo .. min(k_hi, n_old) - 1 of the live part, P rows in flight ---------
   float2 pf[P];
+  float pfw[W ? P : 1];
 #pragma unroll
-  for (int u = 0; u < P; ++u) pf[u] = (k_lo + u < n_old && k_lo + u < k_hi) ? ld2(&colr[(size_t)(k_lo + u) * 64]) : make_float2(0.0f, 0.0f);
+  for (int u = 0; u < P; ++u) {
+    const bool in = k_lo + u < n_old && k_lo + u < k_hi;
+    pf[u] = in ? ld2(&colr[(size_t)(k_lo + u) * 64]) : make_float2(0.0f, 0.0f);
+    if (W) pfw[u] = in ? wcolr[(size_t)(k_lo + u) * 64] : 0.0f;
+  }
   for (int k0 = k_lo; k0 < k_hi; k0 += P) {
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int k = k0 + u;
       if (k < k_hi) {
         const float2 cur = pf[u];
-        if (k + P < k_hi) pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
-        if (k < n_old) step(k, cur.x, cur.y, 0);
-        else if (k < n_tot) step(k, spawned_x(d, p.xs0, k - n_old), d.car_v, 0);  // arrivals queue behind the tail (:97-114)
+        const float curw = W ? pfw[u] : 0.0f;
+        if (k + P < k_hi) {
+          pf[u] = (k + P < n_old) ? ld2(&colr[(size_t)(k + P) * 64]) : make_float2(0.0f, 0.0f);
+          if (W) pfw[u] = (k + P < n_old) ? wcolr[(size_t)(k + P) * 64] : 0.0f;
+        }
+        if (k < n_old) step(k, cur.x, cur.y, curw, 0);
+        else if (k < n_tot) step(k, spawned_x(d, p.xs0, k - n_old), d.car_v, (float)tick, 0);  // arrivals queue behind the tail (:97-114)
       }
     }
   }
@@ -241,8 +265,8 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
     const bool road_ends_here = n_tot > k_lo && n_tot <= k_hi;       // the road's last car is this segment's
     const bool hand_over = n_tot > k_hi && k_hi > k_lo;              // the next segment continues the road behind this one's last car
     if (__builtin_amdgcn_ballot_w64(pend && (road_ends_here || hand_over)) != 0ull) {
-      if (pend && road_ends_here) step(n_tot, 0.0f, 0.0f, 1);
-      else if (pend && hand_over) step(k_hi, 0.0f, 0.0f, 2);
+      if (pend && road_ends_here) step(n_tot, 0.0f, 0.0f, 0.0f, 1);
+      else if (pend && hand_over) step(k_hi, 0.0f, 0.0f, 0.0f, 2);
     }
   }
 
@@ -268,6 +292,7 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
         t.x = hold[q].x;
         t.y = hold[q].y;
         __builtin_nontemporal_store(t, reinterpret_cast<f2v *>(hold_first + (size_t)q * 64));
+        if (W) wcol[(hold_first - col) + (size_t)q * 64] = hold_w[q];
       }
     return 0;
   }
@@ -318,8 +343,9 @@ __device__ __forceinline__ int move_tt_tile_seg(const Dev &d, const long tile, c
 }
 
 // a workgroup = TPW tiles x S segments (S = 2: two tiles; 4, 8: one)
-template <bool AGENT, bool CREC, bool RSW, int S>
-__global__ __launch_bounds__(S == 2 ? 256 : 64 * S) __attribute__((amdgpu_waves_per_eu(S == 2 ? TT_WAVES : 4, S == 2 ? TT_WAVES : 4)))
+template <bool AGENT, bool CREC, bool RSW, int S, bool W = false>
+__global__ __launch_bounds__(S == 2 ? 256 : 64 * S)
+__attribute__((amdgpu_waves_per_eu(S == 2 ? (W ? TT_WAVES_W : TT_WAVES) : 4, S == 2 ? (W ? TT_WAVES_W : TT_WAVES) : 4)))
 void k_move_tts(const Dev d, const int tidx) {
   static_assert(!RSW || (CREC && !AGENT), "road state words: between the pairs of a plain tfx_step call");
   constexpr int TPW = S == 2 ? 2 : 1;
@@ -341,7 +367,7 @@ void k_move_tts(const Dev d, const int tidx) {
     const bool sorted_out = AGENT && active && risk_word(d, env, tidx) == tick + 1;
     const bool two = CREC || !sorted_out;
     if (AGENT && active && !two && lane == 0) risk_any_word(d, tidx) = tick + 1;
-    my_updates += (unsigned long long)move_tt_tile_seg<AGENT, CREC, RSW, S>(d, tile, active, lane, seg, tick, tick_sp, tidx, s_share[tl], two,
+    my_updates += (unsigned long long)move_tt_tile_seg<AGENT, CREC, RSW, S, W>(d, tile, active, lane, seg, tick, tick_sp, tidx, s_share[tl], two,
                                                                           CREC && sorted_out);
     __syncthreads();  // (the LDS words are free for the next tiles)
   }

@@ -624,7 +624,9 @@ int launch_tail_as(tfx_handle h, int tidx, hipStream_t st, int flags) {
   TFX_INJECT(h);
   // (inside agent steps the whole-size workgroups win in the halves as well: measured at cfg2, 128 / 192 / 256 lanes:
   // plain calls 0.399 / 0.406 / 0.414 ms per tick, fused decisions 4.72 / 4.63 / 4.51 ms)
-  const bool halves = h->split_half >= 0 && !AGENT;
+  // (... and so do halves of fewer than two envs per CU: cfg2 x 512 envs 65.1 against 72.5 us per tick, x 1024 112.8 /
+  // 112.1, x 2048 204.9 / 196.1)
+  const bool halves = h->split_half >= 0 && !AGENT && h->d.E >= 2 * h->n_cu;
   const dim3 g(halves ? h->grid_tail_half : h->grid_tail), b(halves ? h->tail_threads_half : h->tail_threads);
   hipLaunchKernelGGL(kern, g, b, lds, st, h->d, tidx, flags);
   HIPCHK(hipGetLastError());

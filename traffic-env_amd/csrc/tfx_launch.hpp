@@ -579,7 +579,8 @@ constexpr size_t TAIL_LDS_MAX = (size_t)160 * 1024;
 bool tail_usable(tfx_handle h) {
   if (!h->tail || (h->poisson && h->d.spawn_stride == 0) || h->d.layout != 1) return false;
   if (tail_lds_bytes(h->d.R, h->d.I, h->het) > TAIL_LDS_MAX) return false;
-  return h->tail == 2 || h->d.E >= h->n_cu;
+  // (the halves of a split call - chosen for the whole range, split_usable - keep k_tail whatever their own size)
+  return h->tail == 2 || h->d.E >= h->n_cu || h->split_half >= 0;
 }
 
 // Two halves on two streams: where each half still runs pairs with k_tail behind them (one env per CU and half).
@@ -590,7 +591,9 @@ bool split_usable(tfx_handle h, int n_ticks) {
   if (!h->split || h->prof || n_ticks < 2 || !pairs_usable(h, n_ticks) || !tail_usable(h)) return false;
   if (h->d.E < 2) return false;
   if (h->split == 2) return true;
-  return h->d.E / 2 >= h->n_cu && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
+  // (round 4, us per tick, two halves / one range: 288 envs 61.7 / 47.6, 320 52.3 / 52.5, 352 63.6 / 52.4, 384 56.8 / 62.3,
+  // 448 60.9 / 66.3, 512 64.3 / 71.4, 768 84.8 / 93.4: from three quarters of an env per CU and half on)
+  return h->d.E / 2 >= h->n_cu * 3 / 4 && (long)(h->d.E / 2) * h->d.G >= (long)h->n_cu * 4;
 }
 
 // Workgroup size (the kernel takes any multiple of 64).  Alone on the chip 256 lanes and as many workgroups as fit; as

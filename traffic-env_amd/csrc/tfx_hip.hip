@@ -44,7 +44,11 @@ extern "C" int tfx_agent_step(tfx_handle h, int32_t n_ticks, int32_t remi, float
   hipStream_t st = (hipStream_t)stream;
   (void)h->d;
   // a batch whose halves still fill the chip: two halves on two streams (k_tail of one under the pass of the other)
-  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks);
+  // (decisions split later than plain calls: fused 10-tick decisions at cfg2, us, two halves / one range - the captured
+  // graph: 384 envs 715 / 687, 448 747 / 726, 512 808 / 796-807, 768 1064 / 1019-1064, 1024 1251 / 1256, 4096 4380 / 4500 -
+  // from two envs per CU and half on)
+  const bool split = !res_usable(h, n_ticks) && !h->poisson && split_usable(h, n_ticks) &&
+                     (h->split == 2 || h->d.E / 2 >= 2 * h->n_cu);
   if (split) {
     if (int rc = ensure_split(h, st)) return rc;
   }
